@@ -1,0 +1,195 @@
+/*
+ * marl_env.h -- C ABI of libmarl_env.so: batched JammerEnv step on MI355X (gfx950).
+ *
+ * The reference (mrutyunjaykumarrao/MARL) is pure Python and has no FFI layer; the
+ * interface each entry point replaces is therefore a Python method or function
+ * of the reference, cited as file:line under /root/reference/src.  All device
+ * pointers are plain HIP device pointers owned by the caller; every call is
+ * asynchronous on the `stream` argument (a hipStream_t passed as void*), does
+ * no host synchronisation, and returns 0 on success or a negative MARL_E* code
+ * (marl_strerror gives the text).
+ *
+ * Layout of the batched state (E environments, N enemies, M jammers), all
+ * row-major and contiguous, struct-of-arrays so that the lanes of one
+ * wavefront read consecutive addresses:
+ *
+ *   enemy_x, enemy_y, enemy_vx, enemy_vy   double [E][N]    EnemySwarm.positions / .velocities
+ *   jam_x, jam_y                           double [E][M]    JammerEnv.jammer_positions
+ *   jam_band                               int32  [E][M]    JammerEnv.jammer_bands
+ *   last_vx, last_vy                       float  [E][M]    JammerEnv.last_velocities (raw action)
+ *   step_count, enemy_band                 int32  [E]
+ *   lambda2_initial                        double [E]
+ *   labels                                 int32  [E][N]    DBSCANClusterer.labels
+ *   cent_x, cent_y, cent_size              [E][N+1]         centroids / cluster_sizes dicts in dict
+ *                                                            order: clusters 0..n_clusters-1, then the
+ *                                                            noise entry (id -1) when present
+ *   n_clusters, ncent                      int32  [E]       clusters (ids >= 0) / dict entries
+ *   prev_x, prev_y, prev_n_clusters, prev_ncent             DBSCANClusterer._prev_centroids
+ *   assign                                 int32  [E][M]    jammer_assignments: cluster id per jammer,
+ *                                                            -1 noise pseudo-cluster, -2 none
+ */
+#ifndef MARL_ENV_H
+#define MARL_ENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MARL_NUM_BANDS 4
+#define MARL_OBS_DIM 5
+#define MARL_ASSIGN_NONE (-2)
+#define MARL_MAX_N 256          /* enemies per env supported by the kernels */
+#define MARL_MAX_M 64           /* jammers per env */
+
+enum {
+    MARL_OK = 0,
+    MARL_EINVAL = -1,           /* bad argument (null pointer, size out of range) */
+    MARL_EUNSUPPORTED = -2,     /* N or M beyond what the kernels support */
+    MARL_EHIP = -3              /* a HIP runtime call failed; see marl_last_hip_error */
+};
+
+/* Constructor arguments of JammerEnv (environment/jammer_env.py:94-127) with the
+ * powers already converted to Watts (physics/fspl.py:50-69), the constants the
+ * reference fixes elsewhere (kappa reward.py:77, noise_std enemy_swarm.py:61,
+ * drift_threshold jammer_env.py:398, spread jammer_env.py:335), and the values
+ * marl_params_init derives from them. */
+typedef struct MarlEnvParams {
+    int32_t N, M;
+    int32_t max_steps, K_recompute, min_samples;
+    int32_t random_jammer_start;
+    int32_t max_reset_attempts;
+    int32_t lambda2_rounds;          /* multisection rounds of the eigenvalue search (0 = default) */
+    double arena_size, dt, v_max, v_enemy;
+    double P_tx_w, P_sens_w, P_jam_w, P_thr_w;
+    double omega[5];
+    double kappa, eps, drift_threshold, spread, noise_std, min_lambda2_initial;
+    /* ---- derived by marl_params_init ---- */
+    double comm_d2_max[MARL_NUM_BANDS];  /* largest squared distance with P_R >= P_sens, per enemy band */
+    double jam_d2_max[MARL_NUM_BANDS];   /* largest squared jammer-midpoint distance with P_jam >= P_thr */
+    double R_jam[MARL_NUM_BANDS];        /* compute_jam_range per enemy band */
+    float dt_f32, v_max_f32, v_max_sq_f32, pad_f32;
+} MarlEnvParams;
+
+typedef struct MarlEnvState {
+    int32_t E;
+    int32_t pad;
+    double *enemy_x, *enemy_y, *enemy_vx, *enemy_vy;
+    double *jam_x, *jam_y;
+    int32_t *jam_band;
+    float *last_vx, *last_vy;
+    int32_t *step_count, *enemy_band;
+    double *lambda2_initial;
+    int32_t *labels;
+    double *cent_x, *cent_y;
+    int32_t *cent_size;
+    int32_t *n_clusters, *ncent;
+    double *prev_x, *prev_y;
+    int32_t *prev_n_clusters, *prev_ncent;
+    int32_t *assign;
+} MarlEnvState;
+
+/* Inputs and outputs of one step.  Optional pointers may be NULL. */
+typedef struct MarlStepIO {
+    const float *actions;      /* [E][M][3]  (vx, vy, band) as the (M,3) action array, jammer_env.py:376-378 */
+    const double *noise;       /* [E][N][2]  enemy velocity noise draw (enemy_swarm.py:165); NULL = counter-based
+                                  generator keyed by (seed, env, step_count) */
+    float *obs;                /* [E][M][5]  out */
+    float *reward;             /* [E]        out */
+    uint8_t *truncated;        /* [E]        out: step_count >= max_steps */
+    double *lambda2;           /* [E]        out, optional: lambda2_current */
+    float *reward_terms;       /* [E][5]     out, optional: unweighted r1..r5 (reward.py:138-153) */
+    double *avg_power_dbm;     /* [E]        out, optional: jammer_env.py:510-560 */
+    uint32_t *adj_bits;        /* [E][N][ceil(N/32)] out, optional: FSPL adjacency before jamming */
+    uint32_t *jam_bits;        /* [E][N][ceil(N/32)] out, optional: disrupted-links mask */
+    uint64_t seed;
+    uint64_t env_offset;       /* global index of env 0 of this shard (multi-GPU: rank * E) */
+} MarlStepIO;
+
+/* Inputs and outputs of a (masked) reset.  Each init pointer may be NULL, in
+ * which case the values are drawn on the device from the counter-based
+ * generator keyed by (seed, env, episode) and the retry loop of
+ * jammer_env.py:283-316 runs in the kernel. */
+typedef struct MarlResetIO {
+    const uint8_t *mask;       /* [E] reset env e iff mask[e] != 0; NULL = all */
+    const double *enemy_pos;   /* [E][N][2] */
+    const double *enemy_vel;   /* [E][N][2] */
+    const int32_t *enemy_band; /* [E] */
+    const double *jam_init;    /* [E][M][2] positions (random_jammer_start) or centroid offsets */
+    const int32_t *jam_band;   /* [E][M] */
+    float *obs;                /* [E][M][5] out (only rows of reset envs are written) */
+    uint64_t seed;
+    uint64_t episode;          /* distinguishes successive resets of one env in generator mode */
+    uint64_t env_offset;
+} MarlResetIO;
+
+/* ---- host-side helpers ---------------------------------------------------- */
+
+/* Fills the derived fields of *p.  comm_d2_max / jam_d2_max are found by
+ * bisection over doubles of the reference's exact float64 chain
+ * P * (lambda / (4*pi*max(sqrt(d2),1e-10)))**2 >= threshold
+ * (physics/fspl.py:199-206), so `d2 <= d2_max` reproduces the reference's
+ * comparison bit for bit. */
+int marl_params_init(MarlEnvParams *p);
+
+/* Bytes of device memory the state of E envs needs, and carving of one
+ * caller-owned allocation `base` (256-byte aligned) into the arrays of *s. */
+size_t marl_state_bytes(const MarlEnvParams *p, int32_t E);
+int marl_state_bind(MarlEnvState *s, const MarlEnvParams *p, int32_t E, void *base);
+
+const char *marl_strerror(int code);
+int marl_last_hip_error(void);
+
+/* ---- the hot path --------------------------------------------------------- */
+
+/* JammerEnv.step for E envs in lockstep (environment/jammer_env.py:356-457):
+ * action decode, enemy random walk, DBSCAN every K_recompute steps with drift
+ * test and proportional reassignment, FSPL adjacency, midpoint jamming mask,
+ * Laplacian lambda2, 5-term reward, observation. */
+int marl_env_step(const MarlEnvParams *p, const MarlEnvState *s, const MarlStepIO *io, void *stream);
+
+/* JammerEnv.reset for the masked envs (environment/jammer_env.py:261-354). */
+int marl_env_reset(const MarlEnvParams *p, const MarlEnvState *s, const MarlResetIO *io, void *stream);
+
+/* ---- separately testable stages -------------------------------------------- */
+
+/* compute_adjacency_matrix (physics/communication_graph.py:41-105) on
+ * x,y [E][N], band [E] -> bits [E][N][ceil(N/32)]. */
+int marl_adjacency_bits(const MarlEnvParams *p, int32_t E, const double *x, const double *y,
+                        const int32_t *band, uint32_t *bits, void *stream);
+
+/* compute_disrupted_links (physics/jamming.py:151-247). */
+int marl_jam_mask_bits(const MarlEnvParams *p, int32_t E, const double *x, const double *y,
+                       const int32_t *band, const double *jam_x, const double *jam_y,
+                       const int32_t *jam_band, uint32_t *bits, void *stream);
+
+/* compute_laplacian + compute_lambda2 (physics/communication_graph.py:184-286)
+ * from adjacency bits [E][N][ceil(N/32)] -> lambda2 [E]. */
+int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t *bits, double *lambda2,
+                           int32_t rounds, void *stream);
+
+/* DBSCANClusterer.fit + get_cluster_sizes (clustering/dbscan_clustering.py:78-144)
+ * -> labels [E][N], cent_x/cent_y/cent_size [E][N+1], n_clusters/ncent [E]. */
+int marl_dbscan(const MarlEnvParams *p, int32_t E, const double *x, const double *y,
+                int32_t *labels, double *cent_x, double *cent_y, int32_t *cent_size,
+                int32_t *n_clusters, int32_t *ncent, void *stream);
+
+/* RolloutBuffer.compute_returns_and_advantages before normalisation
+ * (agents/rollout_buffer.py:151-204), one lane per env:
+ * rewards/values/dones [T][E] float -> advantages/returns [T][E];
+ * gamma and gamma*lam are rounded to float once, as numpy does with Python floats. */
+int marl_gae(int32_t T, int32_t E, const float *rewards, const float *values, const float *dones,
+             const float *last_value, const float *last_done, double gamma, double lam,
+             float *advantages, float *returns, void *stream);
+
+/* The enemy-noise draw the step kernel uses when MarlStepIO.noise is NULL,
+ * written out as [E][N][2] for step numbers step_count[e] + 1. */
+int marl_fill_noise(const MarlEnvParams *p, const MarlEnvState *s, uint64_t seed,
+                    uint64_t env_offset, double *noise, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARL_ENV_H */

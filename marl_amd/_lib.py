@@ -1,0 +1,122 @@
+"""ctypes binding of libmarl_env.so (C ABI declared in include/marl_env.h).
+
+The library is the product path: if it is missing this module raises, there is
+no CPU fallback.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C marl_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmarl_env.so")
+
+NUM_BANDS = 4
+OBS_DIM = 5
+ASSIGN_NONE = -2
+MAX_N = 256
+MAX_M = 64
+
+MARL_OK, MARL_EINVAL, MARL_EUNSUPPORTED, MARL_EHIP = 0, -1, -2, -3
+
+_pd, _pf, _pi, _pu8, _pu32 = (C.c_void_p,) * 5   # device pointers travel as integers
+
+
+class MarlEnvParams(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("M", C.c_int32),
+        ("max_steps", C.c_int32), ("K_recompute", C.c_int32), ("min_samples", C.c_int32),
+        ("random_jammer_start", C.c_int32), ("max_reset_attempts", C.c_int32),
+        ("lambda2_rounds", C.c_int32),
+        ("arena_size", C.c_double), ("dt", C.c_double), ("v_max", C.c_double), ("v_enemy", C.c_double),
+        ("P_tx_w", C.c_double), ("P_sens_w", C.c_double), ("P_jam_w", C.c_double), ("P_thr_w", C.c_double),
+        ("omega", C.c_double * 5),
+        ("kappa", C.c_double), ("eps", C.c_double), ("drift_threshold", C.c_double),
+        ("spread", C.c_double), ("noise_std", C.c_double), ("min_lambda2_initial", C.c_double),
+        ("comm_d2_max", C.c_double * NUM_BANDS), ("jam_d2_max", C.c_double * NUM_BANDS),
+        ("R_jam", C.c_double * NUM_BANDS),
+        ("dt_f32", C.c_float), ("v_max_f32", C.c_float), ("v_max_sq_f32", C.c_float), ("pad_f32", C.c_float),
+    ]
+
+
+_STATE_ARRAYS = [
+    "enemy_x", "enemy_y", "enemy_vx", "enemy_vy", "jam_x", "jam_y", "jam_band", "last_vx", "last_vy",
+    "step_count", "enemy_band", "lambda2_initial", "labels", "cent_x", "cent_y", "cent_size",
+    "n_clusters", "ncent", "prev_x", "prev_y", "prev_n_clusters", "prev_ncent", "assign",
+]
+
+
+class MarlEnvState(C.Structure):
+    _fields_ = [("E", C.c_int32), ("pad", C.c_int32)] + [(n, C.c_void_p) for n in _STATE_ARRAYS]
+
+
+class MarlStepIO(C.Structure):
+    _fields_ = [
+        ("actions", _pf), ("noise", _pd), ("obs", _pf), ("reward", _pf), ("truncated", _pu8),
+        ("lambda2", _pd), ("reward_terms", _pf), ("avg_power_dbm", _pd), ("adj_bits", _pu32),
+        ("jam_bits", _pu32), ("seed", C.c_uint64), ("env_offset", C.c_uint64),
+    ]
+
+
+class MarlResetIO(C.Structure):
+    _fields_ = [
+        ("mask", _pu8), ("enemy_pos", _pd), ("enemy_vel", _pd), ("enemy_band", _pi), ("jam_init", _pd),
+        ("jam_band", _pi), ("obs", _pf), ("seed", C.c_uint64), ("episode", C.c_uint64),
+        ("env_offset", C.c_uint64),
+    ]
+
+
+# every symbol include/marl_env.h declares, with its ctypes signature
+SYMBOLS = {
+    "marl_params_init": (C.c_int, [C.POINTER(MarlEnvParams)]),
+    "marl_state_bytes": (C.c_size_t, [C.POINTER(MarlEnvParams), C.c_int32]),
+    "marl_state_bind": (C.c_int, [C.POINTER(MarlEnvState), C.POINTER(MarlEnvParams), C.c_int32, C.c_void_p]),
+    "marl_strerror": (C.c_char_p, [C.c_int]),
+    "marl_last_hip_error": (C.c_int, []),
+    "marl_env_step": (C.c_int, [C.POINTER(MarlEnvParams), C.POINTER(MarlEnvState), C.POINTER(MarlStepIO),
+                                C.c_void_p]),
+    "marl_env_reset": (C.c_int, [C.POINTER(MarlEnvParams), C.POINTER(MarlEnvState), C.POINTER(MarlResetIO),
+                                 C.c_void_p]),
+    "marl_adjacency_bits": (C.c_int, [C.POINTER(MarlEnvParams), C.c_int32, _pd, _pd, _pi, _pu32, C.c_void_p]),
+    "marl_jam_mask_bits": (C.c_int, [C.POINTER(MarlEnvParams), C.c_int32, _pd, _pd, _pi, _pd, _pd, _pi, _pu32,
+                                     C.c_void_p]),
+    "marl_lambda2_from_bits": (C.c_int, [C.c_int32, C.c_int32, _pu32, _pd, C.c_int32, C.c_void_p]),
+    "marl_dbscan": (C.c_int, [C.POINTER(MarlEnvParams), C.c_int32, _pd, _pd, _pi, _pd, _pd, _pi, _pi, _pi,
+                              C.c_void_p]),
+    "marl_gae": (C.c_int, [C.c_int32, C.c_int32, _pf, _pf, _pf, _pf, _pf, C.c_double, C.c_double, _pf, _pf,
+                           C.c_void_p]),
+    "marl_fill_noise": (C.c_int, [C.POINTER(MarlEnvParams), C.POINTER(MarlEnvState), C.c_uint64, C.c_uint64,
+                                  _pd, C.c_void_p]),
+}
+
+_lib = None
+
+
+class MarlError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmarl_env.so once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MarlError(
+            f"{LIB_PATH} not found: the HIP library is the only implementation of the env step; "
+            "build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what=""):
+    if code != MARL_OK:
+        lib = load()
+        msg = lib.marl_strerror(code).decode()
+        if code == MARL_EHIP:
+            msg += f" (hipError_t {lib.marl_last_hip_error()})"
+        raise MarlError(f"{what}: {msg}" if what else msg)

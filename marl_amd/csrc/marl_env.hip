@@ -1,0 +1,1054 @@
+// libmarl_env.so -- batched JammerEnv step for MI355X (gfx950, wave64).
+//
+// One wavefront advances one environment (N <= 64 enemies): lane i owns enemy i
+// (position, velocity, one 64-bit row of every N x N bit matrix), lanes 0..M-1
+// also own jammer j, lanes 0..ncent-1 a cluster centroid.  Workgroups are a
+// single wave, so the only synchronisation inside a step is wave-level.
+//
+// Arithmetic that decides a boolean or integer output (adjacency, jamming mask,
+// DBSCAN neighbourhoods, reflections, centroid sums) is float64 in the
+// reference's operation order; the file is compiled with -ffp-contract=off so
+// that no multiply-add is fused behind its back, and fma() is written out where
+// fusing is wanted (the eigensolver).
+//
+// Reference files restated here (paths under /root/reference/src):
+//   environment/jammer_env.py   step :356-457, reset :261-354, _compute_lambda2 :464-508,
+//                               _compute_avg_jamming_power :510-560
+//   environment/enemy_swarm.py  _step_random_walk :157-189, reset :244-283
+//   environment/action_space.py apply_action :214-240, clip_bands :202-212
+//   physics/fspl.py             received_power_watts :168-206, compute_jam_range :276-308
+//   physics/jamming.py          compute_disrupted_links :151-247
+//   physics/communication_graph.py  adjacency :41-105, laplacian :184-212, lambda2 :219-286
+//   clustering/dbscan_clustering.py fit :78-128, sizes :130-144, drift :163-204,
+//                               assign (proportional) :263-362, initial positions :365-406
+//   environment/reward.py       compute :106-306
+//   environment/observation.py  build_vectorized :264-332
+//   agents/rollout_buffer.py    compute_returns_and_advantages :151-204
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "marl_env.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr double kSpeedOfLight = 3.0e8;                      // fspl.py:31
+__host__ __device__ inline double band_hz(int b) {            // fspl.py:38-43
+    return b == 0 ? 4.33e8 : (b == 1 ? 9.15e8 : (b == 2 ? 2.40e9 : 5.80e9));
+}
+constexpr double kFourPi = 12.566370614359172;               // 4 * np.pi as numpy evaluates it
+constexpr double kTwoPi = 6.283185307179586;
+
+thread_local int g_last_hip_error = 0;
+
+// ------------------------------------------------------------------ wave helpers
+#define WSYNC() __syncthreads()   /* workgroup == one wave */
+
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p ? 1 : 0); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src); }
+
+// ------------------------------------------------------------------ counter-based generator
+// Philox4x32-10 (Salmon et al., SC'11).  Counter = (env index, draw index, stream id, episode/step),
+// key = seed.  Same values whatever the launch geometry.
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {   // (0,1), 53 bits
+    const uint64_t v = ((uint64_t)hi << 21) ^ (uint64_t)(lo >> 11);
+    return ((double)(v & ((1ull << 53) - 1)) + 0.5) * (1.0 / 9007199254740992.0);
+}
+enum { STREAM_NOISE = 1, STREAM_RESET_ENEMY = 2, STREAM_RESET_JAMMER = 3, STREAM_RESET_ENV = 4 };
+
+// Two independent N(0, sigma) draws for enemy `i` of env `genv` at step `step`.
+__device__ __forceinline__ void noise_pair(uint64_t seed, uint64_t genv, uint32_t step, uint32_t i,
+                                           double sigma, double& nx, double& ny) {
+    uint32_t r[4];
+    philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ (i << 8) ^ STREAM_NOISE, step, i,
+               (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
+    const double rad = sqrt(-2.0 * log(u1)) * sigma;
+    double s, c;
+    sincos(kTwoPi * u2, &s, &c);
+    nx = rad * c; ny = rad * s;
+}
+
+// ------------------------------------------------------------------ LDS layout of one env
+struct WaveLds {
+    double sx[WAVE], sy[WAVE];        // enemy positions
+    double jx[WAVE], jy[WAVE];        // jammer positions
+    double u[WAVE], q[WAVE];          // Householder vectors
+    double dd[WAVE], e2[WAVE];        // tridiagonal: diagonal, squared off-diagonal
+    double cx[WAVE + 2], cy[WAVE + 2];  // centroids in dict order
+    double px[WAVE + 2], py[WAVE + 2];  // previous centroids
+    int csz[WAVE + 2];
+    int lab[WAVE];
+    int asg[WAVE];
+    int jb[WAVE];
+};
+
+__host__ __device__ inline int mat_ld(int n) { return n | 1; }   // odd leading dimension: conflict-free column reads
+inline size_t wave_lds_bytes(int n) { return sizeof(WaveLds) + (size_t)n * mat_ld(n) * sizeof(double); }
+
+// ------------------------------------------------------------------ pairwise bit rows
+// Row `lane` of the FSPL adjacency (communication_graph.py:41-105): bit j set iff
+// (xi-xj)^2 + (yi-yj)^2 <= d2max, diagonal clear.
+__device__ __forceinline__ uint64_t adjacency_row(const WaveLds& L, int n, int lane, double d2max) {
+    uint64_t row = 0;
+    const double xi = L.sx[lane & (WAVE - 1)], yi = L.sy[lane & (WAVE - 1)];
+    for (int j = 0; j < n; ++j) {
+        const double dx = xi - L.sx[j], dy = yi - L.sy[j];
+        const double d2 = dx * dx + dy * dy;
+        row |= (uint64_t)(d2 <= d2max) << j;
+    }
+    row &= ~(1ull << lane);
+    return lane < n ? row : 0ull;
+}
+
+// Row `lane` of the disrupted-links mask (jamming.py:151-247): bit j set iff some
+// jammer k on the enemy band has |q_k - (p_i + p_j)/2|^2 <= d2max; diagonal clear.
+__device__ __forceinline__ uint64_t jam_row(const WaveLds& L, int n, int m, int lane, int eband, double d2max) {
+    uint64_t row = 0;
+    const double xi = L.sx[lane & (WAVE - 1)], yi = L.sy[lane & (WAVE - 1)];
+    for (int k = 0; k < m; ++k) {
+        if (L.jb[k] != eband) continue;          // wave-uniform
+        const double qx = L.jx[k], qy = L.jy[k];
+        for (int j = 0; j < n; ++j) {
+            const double mx = (xi + L.sx[j]) / 2, my = (yi + L.sy[j]) / 2;
+            const double dx = qx - mx, dy = qy - my;
+            const double d2 = dx * dx + dy * dy;
+            row |= (uint64_t)(d2 <= d2max) << j;
+        }
+    }
+    row &= ~(1ull << lane);
+    return lane < n ? row : 0ull;
+}
+
+// ------------------------------------------------------------------ lambda2
+// Second-smallest eigenvalue of L = D - A for the graph whose adjacency rows are
+// `row` (communication_graph.py:184-286; the reference calls LAPACK dsyevr through
+// scipy.linalg.eigh(subset_by_index=[0,1])).  Here: exact shortcuts for the
+// complete graph (lambda2 = n) and for disconnected graphs (lambda2 = 0), else
+// Householder tridiagonalisation of L in LDS (lane j owns row j) followed by a
+// 64-way multisection on the Sturm count of the tridiagonal matrix.
+__device__ double lambda2_wave(uint64_t row, int n, int lane, WaveLds& L, double* A, int rounds) {
+    if (n <= 1) return 0.0;
+    const int deg = __popcll(row);
+    const uint64_t active = (n >= 64) ? ~0ull : ((1ull << n) - 1);
+    if (ballot64(lane < n && deg == n - 1) == active) return (double)n;
+    {   // connectivity: breadth-first search from vertex 0, one ballot per level
+        uint64_t comp = 1ull, frontier = 1ull;
+        while (frontier) {
+            const uint64_t hit = ballot64((row & frontier) != 0);
+            const uint64_t nw = hit & ~comp;
+            comp |= nw;
+            frontier = nw;
+        }
+        if (comp != active) return 0.0;
+    }
+    const int ld = mat_ld(n);
+    if (lane < n) {
+        double* Ar = A + lane * ld;
+        for (int k = 0; k < n; ++k) Ar[k] = (k == lane) ? (double)deg : -(double)((row >> k) & 1ull);
+    }
+    WSYNC();
+    for (int i = n - 1; i >= 2; --i) {
+        const int l = i - 1;
+        double uj = (lane <= l) ? A[i * ld + lane] : 0.0;
+        double h = wave_sum(uj * uj);
+        if (lane == 0) { L.dd[i] = A[i * ld + i]; L.e2[i] = h; }
+        if (h == 0.0) continue;                       // row already reduced
+        const double f = bcast(uj, l);
+        const double g = (f >= 0.0) ? -sqrt(h) : sqrt(h);
+        h -= f * g;
+        if (lane == l) uj = f - g;
+        L.u[lane] = uj;
+        WSYNC();
+        double p = 0.0;
+        if (lane <= l) {
+            const double* Ar = A + lane * ld;
+            double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+            int k = 0;
+            for (; k + 3 <= l; k += 4) {
+                p0 = fma(Ar[k], L.u[k], p0);
+                p1 = fma(Ar[k + 1], L.u[k + 1], p1);
+                p2 = fma(Ar[k + 2], L.u[k + 2], p2);
+                p3 = fma(Ar[k + 3], L.u[k + 3], p3);
+            }
+            for (; k <= l; ++k) p0 = fma(Ar[k], L.u[k], p0);
+            p = ((p0 + p1) + (p2 + p3)) / h;
+        }
+        const double K = wave_sum(uj * p) / (h + h);
+        const double qj = p - K * uj;
+        L.q[lane] = qj;
+        WSYNC();
+        if (lane <= l) {
+            double* Ar = A + lane * ld;
+            for (int k = 0; k <= l; ++k) Ar[k] = fma(-uj, L.q[k], fma(-qj, L.u[k], Ar[k]));
+        }
+        WSYNC();
+    }
+    if (lane == 0) {
+        L.dd[1] = A[ld + 1];
+        L.e2[1] = A[ld] * A[ld];
+        L.dd[0] = A[0];
+        L.e2[0] = 0.0;
+    }
+    WSYNC();
+    // multisection: lane t counts eigenvalues below x_t; the second-smallest lies
+    // between the last x with count <= 1 and the first with count >= 2.
+    double lo = -1e-7, hi = (double)n * (1.0 + 1e-9) + 1e-7;
+    const double pivmin = 1e-290;
+    for (int r = 0; r < rounds; ++r) {
+        const double w = (hi - lo) * (1.0 / 65.0);
+        const double x = lo + w * (double)(lane + 1);
+        double qv = L.dd[0] - x;
+        int cnt = qv < 0.0;
+        for (int i = 1; i < n; ++i) {
+            if (fabs(qv) < pivmin) qv = -pivmin;
+            double rc = __builtin_amdgcn_rcp(qv);
+            rc = fma(fma(-qv, rc, 1.0), rc, rc);
+            qv = (L.dd[i] - x) - L.e2[i] * rc;
+            cnt += qv < 0.0;
+        }
+        const uint64_t ge2 = ballot64(cnt >= 2);
+        if (ge2 == 0) {
+            lo = bcast(x, WAVE - 1);
+        } else {
+            const int t = __ffsll((unsigned long long)ge2) - 1;
+            const double xh = bcast(x, t);
+            const double xl = bcast(x, t > 0 ? t - 1 : 0);
+            hi = xh;
+            if (t > 0) lo = xl;
+        }
+    }
+    return 0.5 * (lo + hi);
+}
+
+// ------------------------------------------------------------------ DBSCAN + centroids
+// Labels of sklearn DBSCAN(eps, min_samples) on the positions in L.sx/L.sy
+// (dbscan_clustering.py:113), then centroids / sizes in dict order
+// (dbscan_clustering.py:116-128, 130-144, 230-260) into L.cx/L.cy/L.csz.
+// Returns the lane's label; n_clusters and ncent by reference (wave-uniform).
+__device__ int dbscan_wave(const MarlEnvParams& P, int n, int lane, WaveLds& L, int& n_clusters, int& ncent) {
+    const double eps2 = P.eps * P.eps;
+    uint64_t nb = 0;
+    {
+        const double xi = L.sx[lane & (WAVE - 1)], yi = L.sy[lane & (WAVE - 1)];
+        for (int j = 0; j < n; ++j) {
+            const double dx = xi - L.sx[j], dy = yi - L.sy[j];
+            const double d2 = dx * dx + dy * dy;
+            nb |= (uint64_t)(d2 <= eps2) << j;
+        }
+        if (lane >= n) nb = 0;
+    }
+    const uint64_t core = ballot64(lane < n && __popcll(nb) >= P.min_samples);
+    int label = -1;
+    int num = 0;
+    uint64_t unvisited = core;
+    while (unvisited) {
+        const int s = __ffsll((unsigned long long)unvisited) - 1;
+        uint64_t comp = 1ull << s, frontier = comp, reached = 0;
+        while (frontier) {   // expand through core points only; remember every point touched
+            const uint64_t hit = ballot64((nb & frontier) != 0);
+            reached |= hit;
+            const uint64_t nw = hit & core & ~comp;
+            comp |= nw;
+            frontier = nw;
+        }
+        const uint64_t members = comp | (reached & ~core);   // core component + its border points
+        if (((members >> lane) & 1ull) && label == -1) label = num;
+        unvisited &= ~comp;
+        ++num;
+    }
+    L.lab[lane] = label;
+    const bool has_noise = ballot64(lane < n && label == -1) != 0;
+    const int entries = num + (has_noise ? 1 : 0);
+    WSYNC();
+    for (int c = lane; c < entries; c += WAVE) {
+        const int id = (c < num) ? c : -1;
+        double ax = 0.0, ay = 0.0;
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) {          // np.mean(axis=0): sequential sum in index order
+            if (L.lab[i] == id) { ax = ax + L.sx[i]; ay = ay + L.sy[i]; ++cnt; }
+        }
+        L.cx[c] = ax / (double)cnt;
+        L.cy[c] = ay / (double)cnt;
+        L.csz[c] = cnt;
+    }
+    n_clusters = num;
+    ncent = entries;
+    if (num == 0) {                            // all noise: fallback centroid at the arena centre
+        if (lane == 0) { L.cx[0] = P.arena_size / 2; L.cy[0] = P.arena_size / 2; L.csz[0] = n; }
+        ncent = 1;
+    }
+    WSYNC();
+    return label;
+}
+
+// should_reassign_jammers(drift_threshold) (dbscan_clustering.py:163-204) on the
+// current (L.cx..) and previous (L.px..) centroid tables.
+__device__ bool should_reassign_wave(const MarlEnvParams& P, int lane, const WaveLds& L, int num, int ncent,
+                                     int pnum, int pncent) {
+    bool mine = false;
+    for (int s = lane; s < ncent; s += WAVE) {
+        const int id = (s < num) ? s : -1;
+        const bool in_prev = (id >= 0) ? (id < pnum) : (pncent > pnum);
+        if (!in_prev) { mine = true; continue; }              // new cluster id: drift = inf
+        const int ps = (id >= 0) ? id : pnum;
+        const double dx = L.cx[s] - L.px[ps], dy = L.cy[s] - L.py[ps];
+        if (sqrt(dx * dx + dy * dy) > P.drift_threshold) mine = true;
+    }
+    return ballot64(mine) != 0 || ncent != pncent;
+}
+
+// assign_jammers_to_clusters(strategy="proportional") (dbscan_clustering.py:263-362) into L.asg.
+__device__ void assign_proportional_wave(int m, int lane, WaveLds& L, int num, int ncent) {
+    if (lane == 0 && m > 0 && ncent > 0) {
+        const int first = 0;
+        const int nvalid = (num > 0) ? num : ncent;        // all-noise: the -1 entry is the one cluster
+        int total = 0;
+        for (int s = first; s < nvalid; ++s) total += L.csz[s];
+        if (total == 0) total = nvalid;
+        int j = 0, remaining = m;
+        for (int s = 0; s < nvalid; ++s) {
+            const int id = (num > 0) ? s : -1;
+            int count;
+            if (s == nvalid - 1) {
+                count = remaining;
+            } else {
+                count = (int)((double)(m * L.csz[s]) / (double)total);
+                if (count < 1) count = 1;
+                if (count > remaining) count = remaining;
+            }
+            for (int t = 0; t < count; ++t) L.asg[j + t] = id;
+            j += count;
+            remaining -= count;
+        }
+    }
+    WSYNC();
+}
+
+// ------------------------------------------------------------------ reward + observation
+struct RewardOut { double total; float r[5]; };
+
+// RewardCalculator.compute (reward.py:106-306) and ObservationBuilder.build_vectorized
+// (observation.py:264-332).  Lane j < m owns jammer j.  obs_row receives the five
+// features of the lane's jammer.
+__device__ RewardOut reward_obs_wave(const MarlEnvParams& P, int n, int m, int lane, const WaveLds& L,
+                                     int eband, int num, int ncent, double lam, double lam0,
+                                     float raw_vx, float raw_vy, float obs_row[5]) {
+    RewardOut out;
+    const bool act = lane < m;
+    const double A = P.arena_size;
+    const double xj = L.jx[lane & (WAVE - 1)], yj = L.jy[lane & (WAVE - 1)];
+    const double Rjam = P.R_jam[eband];
+    // nearest centroid over every dict entry, first minimum wins
+    double best = INFINITY;
+    int bslot = 0;
+    for (int s = 0; s < ncent; ++s) {
+        const double dx = xj - L.cx[s], dy = yj - L.cy[s];
+        const double d = sqrt(dx * dx + dy * dy);
+        if (d < best) { best = d; bslot = s; }
+    }
+    // pairwise jammer distances: overlap count (pairs k > j) and mean distance to the others
+    const double thr = 2 * Rjam;
+    int ov = 0;
+    double dsum = 0.0;
+    for (int k = 0; k < m; ++k) {
+        const double dx = xj - L.jx[k], dy = yj - L.jy[k];
+        const double d = sqrt(dx * dx + dy * dy);
+        if (k != lane) dsum = dsum + d;
+        if (k > lane && d < thr) ++ov;
+    }
+    const int ovl = wave_sum(act ? ov : 0);
+    const double r5 = (m > 1) ? (double)ovl / ((double)(m * (m - 1)) / 2) : 0.0;
+    const int match = (act && L.jb[lane & (WAVE - 1)] == eband) ? 1 : 0;
+    const int nmatch = wave_sum(match);
+    // term 1 (reward.py:178-199)
+    double r1 = 0.0;
+    if (lam0 > 0.0) {
+        const double lc = lam > 0.0 ? lam : 0.0;
+        r1 = 1.0 - (lc / lam0);
+        r1 = fmin(fmax(r1, 0.0), 1.0);
+    }
+    const double r2 = (double)nmatch / (double)m;
+    // term 3 (reward.py:218-260): assigned centroid if its id still exists, else nearest
+    double prox = 0.0;
+    if (act && ncent > 0) {
+        const int c = L.asg[lane];
+        int slot = bslot;
+        if (c >= 0 && c < num) slot = c;
+        else if (c == -1 && ncent > num) slot = num;
+        const double dx = xj - L.cx[slot], dy = yj - L.cy[slot];
+        prox = exp(-P.kappa * sqrt(dx * dx + dy * dy));
+    }
+    const double r3 = wave_sum(prox) / (double)m;
+    // term 4 (reward.py:262-280), float32 like the reference's float32 action path
+    float en = 0.0f;
+    if (act) en = (raw_vx * raw_vx + raw_vy * raw_vy) / P.v_max_sq_f32;
+    const float r4 = wave_sum(en) / (float)m;
+    const double raw = P.omega[0] * r1 + P.omega[1] * r2 + P.omega[2] * r3 - P.omega[3] * (double)r4 - P.omega[4] * r5;
+    out.total = fmin(fmax(raw, -10.0), 10.0);
+    out.r[0] = (float)r1; out.r[1] = (float)r2; out.r[2] = (float)r3; out.r[3] = r4; out.r[4] = (float)r5;
+    // observation
+    obs_row[0] = (float)fmin(fmax(best / A, 0.0), 1.0);
+    obs_row[1] = (n > 0 && ncent > 0) ? (float)((double)L.csz[bslot] / (double)n) : 0.0f;
+    obs_row[2] = (m > 1) ? (float)fmin(fmax(dsum / (double)(m - 1) / A, 0.0), 1.0) : 0.5f;
+    obs_row[3] = (float)r5;
+    obs_row[4] = match ? 1.0f : 0.0f;
+    return out;
+}
+
+// _compute_avg_jamming_power (jammer_env.py:510-560): mean over links i<j of the
+// strongest matching jammer's power at the link midpoint, in dBm; -80 when none.
+__device__ double avg_power_wave(const MarlEnvParams& P, int n, int m, int lane, const WaveLds& L, int eband) {
+    int nm = 0;
+    for (int k = 0; k < m; ++k) nm += (L.jb[k] == eband);
+    if (nm == 0) return -80.0;
+    const double wl = kSpeedOfLight / band_hz(eband);
+    const double xi = L.sx[lane & (WAVE - 1)], yi = L.sy[lane & (WAVE - 1)];
+    double psum = 0.0;
+    int pcnt = 0;
+    for (int j = 0; j < n; ++j) {
+        double dmin = INFINITY;
+        const double mx = (xi + L.sx[j]) / 2, my = (yi + L.sy[j]) / 2;
+        for (int k = 0; k < m; ++k) {
+            if (L.jb[k] != eband) continue;
+            const double dx = L.jx[k] - mx, dy = L.jy[k] - my;
+            dmin = fmin(dmin, dx * dx + dy * dy);
+        }
+        if (lane < n && j > lane) {
+            const double d = fmax(sqrt(dmin), 1e-10);
+            const double g = wl / (kFourPi * d);
+            const double pw = P.P_jam_w * (g * g);
+            if (pw > 0.0) { psum += pw; ++pcnt; }
+        }
+    }
+    const double tot = wave_sum(psum);
+    const int cnt = wave_sum(pcnt);
+    if (cnt == 0) return -80.0;
+    return 10.0 * log10(tot / (double)cnt) + 30.0;
+}
+
+__device__ __forceinline__ void store_bits(uint32_t* dst, int e, int n, int lane, uint64_t row) {
+    if (dst == nullptr || lane >= n) return;
+    const int W = (n + 31) / 32;
+    uint32_t* p = dst + ((size_t)e * n + lane) * W;
+    p[0] = (uint32_t)row;
+    if (W > 1) p[1] = (uint32_t)(row >> 32);
+}
+
+__device__ __forceinline__ WaveLds& carve(unsigned char* smem, double*& A) {
+    WaveLds& L = *reinterpret_cast<WaveLds*>(smem);
+    A = reinterpret_cast<double*>(smem + sizeof(WaveLds));
+    return L;
+}
+
+// ------------------------------------------------------------------ step kernel (N <= 64)
+__global__ __launch_bounds__(WAVE) void env_step_wave_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* A;
+    WaveLds& L = carve(smem, A);
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int n = P.N, m = P.M, KS = n + 1;
+    const int step = S.step_count[e] + 1;
+    const int eband = S.enemy_band[e];
+    const double arena = P.arena_size;
+
+    // -- action decode (jammer_env.py:372-388, action_space.py:190-240)
+    float raw_vx = 0.0f, raw_vy = 0.0f;
+    if (lane < m) {
+        const float* a = io.actions + ((size_t)e * m + lane) * 3;
+        raw_vx = a[0]; raw_vy = a[1];
+        int band = (int)a[2];                                  // astype(int32): truncation
+        band = band < 0 ? 0 : (band > MARL_NUM_BANDS - 1 ? MARL_NUM_BANDS - 1 : band);
+        const float cvx = fminf(fmaxf(raw_vx, -P.v_max_f32), P.v_max_f32);
+        const float cvy = fminf(fmaxf(raw_vy, -P.v_max_f32), P.v_max_f32);
+        const float sx_ = cvx * P.dt_f32, sy_ = cvy * P.dt_f32;   // float32 product, as numpy does for f32 actions
+        double x = S.jam_x[(size_t)e * m + lane] + (double)sx_;
+        double y = S.jam_y[(size_t)e * m + lane] + (double)sy_;
+        x = fmin(fmax(x, 0.0), arena);
+        y = fmin(fmax(y, 0.0), arena);
+        S.jam_x[(size_t)e * m + lane] = x;
+        S.jam_y[(size_t)e * m + lane] = y;
+        S.jam_band[(size_t)e * m + lane] = band;
+        S.last_vx[(size_t)e * m + lane] = raw_vx;
+        S.last_vy[(size_t)e * m + lane] = raw_vy;
+        L.jx[lane] = x; L.jy[lane] = y; L.jb[lane] = band;
+        L.asg[lane] = S.assign[(size_t)e * m + lane];
+    }
+    // -- enemy random walk (enemy_swarm.py:157-189)
+    if (lane < n) {
+        const size_t o = (size_t)e * n + lane;
+        double nx, ny;
+        if (io.noise) { nx = io.noise[o * 2]; ny = io.noise[o * 2 + 1]; }
+        else noise_pair(io.seed, io.env_offset + e, (uint32_t)step, (uint32_t)lane, P.noise_std, nx, ny);
+        double vx = S.enemy_vx[o] + nx, vy = S.enemy_vy[o] + ny;
+        double sp = sqrt(vx * vx + vy * vy);
+        sp = fmax(sp, 1e-6);
+        vx = vx / sp * P.v_enemy;
+        vy = vy / sp * P.v_enemy;
+        double x = S.enemy_x[o] + vx * P.dt, y = S.enemy_y[o] + vy * P.dt;
+        if (x < 0.0) { x = -x; vx = -vx; }
+        if (x > arena) { x = 2 * arena - x; vx = -vx; }
+        if (y < 0.0) { y = -y; vy = -vy; }
+        if (y > arena) { y = 2 * arena - y; vy = -vy; }
+        x = fmin(fmax(x, 0.0), arena);
+        y = fmin(fmax(y, 0.0), arena);
+        S.enemy_x[o] = x; S.enemy_y[o] = y; S.enemy_vx[o] = vx; S.enemy_vy[o] = vy;
+        L.sx[lane] = x; L.sy[lane] = y;
+    }
+    int num = S.n_clusters[e], ncent = S.ncent[e];
+    WSYNC();
+    // -- clusters: recompute every K steps (jammer_env.py:394-402), else load the table
+    if (step % P.K_recompute == 0) {
+        const int pnum = num, pncent = ncent;
+        for (int s = lane; s < pncent; s += WAVE) {      // centroids -> _prev_centroids
+            L.px[s] = S.cent_x[(size_t)e * KS + s];
+            L.py[s] = S.cent_y[(size_t)e * KS + s];
+        }
+        const int label = dbscan_wave(P, n, lane, L, num, ncent);
+        if (lane < n) S.labels[(size_t)e * n + lane] = label;
+        for (int s = lane; s < pncent; s += WAVE) {
+            S.prev_x[(size_t)e * KS + s] = L.px[s];
+            S.prev_y[(size_t)e * KS + s] = L.py[s];
+        }
+        for (int s = lane; s < ncent; s += WAVE) {
+            S.cent_x[(size_t)e * KS + s] = L.cx[s];
+            S.cent_y[(size_t)e * KS + s] = L.cy[s];
+            S.cent_size[(size_t)e * KS + s] = L.csz[s];
+        }
+        if (lane == 0) {
+            S.prev_n_clusters[e] = pnum; S.prev_ncent[e] = pncent;
+            S.n_clusters[e] = num; S.ncent[e] = ncent;
+        }
+        if (should_reassign_wave(P, lane, L, num, ncent, pnum, pncent)) {
+            assign_proportional_wave(m, lane, L, num, ncent);
+            if (lane < m) S.assign[(size_t)e * m + lane] = L.asg[lane];
+        }
+    } else {
+        for (int s = lane; s < ncent; s += WAVE) {
+            L.cx[s] = S.cent_x[(size_t)e * KS + s];
+            L.cy[s] = S.cent_y[(size_t)e * KS + s];
+            L.csz[s] = S.cent_size[(size_t)e * KS + s];
+        }
+        WSYNC();
+    }
+    // -- lambda2 of the jammed graph (jammer_env.py:464-508)
+    const uint64_t adj = adjacency_row(L, n, lane, P.comm_d2_max[eband]);
+    const uint64_t jam = jam_row(L, n, m, lane, eband, P.jam_d2_max[eband]);
+    store_bits(io.adj_bits, e, n, lane, adj);
+    store_bits(io.jam_bits, e, n, lane, jam);
+    const double lam = lambda2_wave(adj & ~jam, n, lane, L, A, P.lambda2_rounds);
+    const double lam0 = S.lambda2_initial[e];
+    // -- reward, observation (jammer_env.py:414-438)
+    float obs_row[5];
+    const RewardOut rw = reward_obs_wave(P, n, m, lane, L, eband, num, ncent, lam, lam0, raw_vx, raw_vy, obs_row);
+    if (lane < m) {
+        float* o = io.obs + ((size_t)e * m + lane) * MARL_OBS_DIM;
+#pragma unroll
+        for (int c = 0; c < MARL_OBS_DIM; ++c) o[c] = obs_row[c];
+    }
+    if (io.reward_terms && lane < 5) io.reward_terms[(size_t)e * 5 + lane] = rw.r[lane];
+    double avgp = 0.0;
+    if (io.avg_power_dbm) avgp = avg_power_wave(P, n, m, lane, L, eband);
+    if (lane == 0) {
+        S.step_count[e] = step;
+        io.reward[e] = (float)rw.total;
+        io.truncated[e] = (uint8_t)(step >= P.max_steps);
+        if (io.lambda2) io.lambda2[e] = lam;
+        if (io.avg_power_dbm) io.avg_power_dbm[e] = avgp;
+    }
+}
+
+// ------------------------------------------------------------------ reset kernel (N <= 64)
+__global__ __launch_bounds__(WAVE) void env_reset_wave_kernel(MarlEnvParams P, MarlEnvState S, MarlResetIO io) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* A;
+    WaveLds& L = carve(smem, A);
+    const int e = blockIdx.x, lane = threadIdx.x;
+    if (io.mask && io.mask[e] == 0) return;
+    const int n = P.N, m = P.M, KS = n + 1;
+    const double arena = P.arena_size;
+    const uint64_t genv = io.env_offset + e;
+    const uint32_t k0 = (uint32_t)io.seed, k1 = (uint32_t)(io.seed >> 32);
+    int num = S.n_clusters[e], ncent = S.ncent[e];
+    int eband = 2;
+    double lam0 = 0.0;
+    const bool host_init = io.enemy_pos != nullptr;
+    const int attempts = host_init ? 1 : (P.max_reset_attempts > 0 ? P.max_reset_attempts : 1);
+    for (int attempt = 0; attempt < attempts; ++attempt) {
+        // EnemySwarm.reset (enemy_swarm.py:244-283): uniform positions in [0.1A, 0.9A], uniform headings
+        if (lane < n) {
+            const size_t o = (size_t)e * n + lane;
+            double x, y, vx, vy;
+            if (host_init) {
+                x = io.enemy_pos[o * 2]; y = io.enemy_pos[o * 2 + 1];
+                vx = io.enemy_vel[o * 2]; vy = io.enemy_vel[o * 2 + 1];
+            } else {
+                uint32_t r[4], r2[4];
+                philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)lane << 8) ^ STREAM_RESET_ENEMY,
+                           (uint32_t)io.episode, (uint32_t)attempt, k0, k1, r);
+                philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)lane << 8) ^ STREAM_RESET_ENEMY,
+                           (uint32_t)io.episode, (uint32_t)attempt | 0x80000000u, k0, k1, r2);
+                const double margin = arena * 0.1;
+                x = margin + (arena - margin - margin) * u01(r[0], r[1]);
+                y = margin + (arena - margin - margin) * u01(r[2], r[3]);
+                double s, c;
+                sincos(kTwoPi * u01(r2[0], r2[1]), &s, &c);
+                vx = P.v_enemy * c; vy = P.v_enemy * s;
+            }
+            S.enemy_x[o] = x; S.enemy_y[o] = y; S.enemy_vx[o] = vx; S.enemy_vy[o] = vy;
+            L.sx[lane] = x; L.sy[lane] = y;
+        }
+        if (io.enemy_band) {
+            eband = io.enemy_band[e];
+        } else {
+            uint32_t r[4];
+            philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ STREAM_RESET_ENV, (uint32_t)io.episode,
+                       (uint32_t)attempt, k0, k1, r);
+            eband = (int)(r[0] & 3u);
+        }
+        eband = eband < 0 ? 0 : (eband > 3 ? 3 : eband);
+        WSYNC();
+        // _update_clusters (jammer_env.py:298): previous table <- current table, then fit
+        const int pnum = num, pncent = ncent;
+        for (int s = lane; s < pncent; s += WAVE) {
+            S.prev_x[(size_t)e * KS + s] = S.cent_x[(size_t)e * KS + s];
+            S.prev_y[(size_t)e * KS + s] = S.cent_y[(size_t)e * KS + s];
+        }
+        WSYNC();
+        const int label = dbscan_wave(P, n, lane, L, num, ncent);
+        if (lane < n) S.labels[(size_t)e * n + lane] = label;
+        for (int s = lane; s < ncent; s += WAVE) {
+            S.cent_x[(size_t)e * KS + s] = L.cx[s];
+            S.cent_y[(size_t)e * KS + s] = L.cy[s];
+            S.cent_size[(size_t)e * KS + s] = L.csz[s];
+        }
+        if (lane == 0) {
+            S.prev_n_clusters[e] = pnum; S.prev_ncent[e] = pncent;
+            S.n_clusters[e] = num; S.ncent[e] = ncent;
+        }
+        WSYNC();
+        // lambda2 of the un-jammed graph (jammer_env.py:301)
+        const uint64_t adj = adjacency_row(L, n, lane, P.comm_d2_max[eband]);
+        lam0 = lambda2_wave(adj, n, lane, L, A, P.lambda2_rounds);
+        if (lam0 >= P.min_lambda2_initial) break;
+    }
+    // jammers (jammer_env.py:321-339)
+    if (P.random_jammer_start) {
+        if (lane < m) L.asg[lane] = MARL_ASSIGN_NONE;
+        WSYNC();
+    } else {
+        if (lane < m) L.asg[lane] = MARL_ASSIGN_NONE;
+        WSYNC();
+        assign_proportional_wave(m, lane, L, num, ncent);
+    }
+    if (lane < m) {
+        const size_t o = (size_t)e * m + lane;
+        double ix, iy;
+        int band;
+        uint32_t r[4], r2[4];
+        if (io.jam_init == nullptr || io.jam_band == nullptr) {
+            philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)lane << 8) ^ STREAM_RESET_JAMMER,
+                       (uint32_t)io.episode, 0u, k0, k1, r);
+            philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)lane << 8) ^ STREAM_RESET_JAMMER,
+                       (uint32_t)io.episode, 1u, k0, k1, r2);
+        }
+        if (io.jam_init) { ix = io.jam_init[o * 2]; iy = io.jam_init[o * 2 + 1]; }
+        else if (P.random_jammer_start) {
+            ix = 0.1 * arena + (0.9 * arena - 0.1 * arena) * u01(r[0], r[1]);
+            iy = 0.1 * arena + (0.9 * arena - 0.1 * arena) * u01(r[2], r[3]);
+        } else {
+            ix = -P.spread + (P.spread + P.spread) * u01(r[0], r[1]);
+            iy = -P.spread + (P.spread + P.spread) * u01(r[2], r[3]);
+        }
+        band = io.jam_band ? io.jam_band[o] : (int)(r2[0] & 3u);
+        double x = ix, y = iy;
+        if (!P.random_jammer_start) {       // get_jammer_initial_positions: clip(centroid + offset)
+            const int c = L.asg[lane];
+            x = 0.0; y = 0.0;
+            int slot = -1;
+            if (c >= 0 && c < num) slot = c;
+            else if (c == -1 && ncent > num) slot = num;
+            if (slot >= 0) {
+                x = fmin(fmax(L.cx[slot] + ix, 0.0), arena);
+                y = fmin(fmax(L.cy[slot] + iy, 0.0), arena);
+            }
+        }
+        S.jam_x[o] = x; S.jam_y[o] = y; S.jam_band[o] = band;
+        S.last_vx[o] = 0.0f; S.last_vy[o] = 0.0f;
+        S.assign[o] = L.asg[lane];
+        L.jx[lane] = x; L.jy[lane] = y; L.jb[lane] = band;
+    }
+    WSYNC();
+    float obs_row[5];
+    (void)reward_obs_wave(P, n, m, lane, L, eband, num, ncent, lam0, lam0, 0.0f, 0.0f, obs_row);
+    if (lane < m && io.obs) {
+        float* o = io.obs + ((size_t)e * m + lane) * MARL_OBS_DIM;
+#pragma unroll
+        for (int c = 0; c < MARL_OBS_DIM; ++c) o[c] = obs_row[c];
+    }
+    if (lane == 0) {
+        S.step_count[e] = 0;
+        S.enemy_band[e] = eband;
+        S.lambda2_initial[e] = lam0;
+    }
+}
+
+// ------------------------------------------------------------------ stage kernels (N <= 64)
+__global__ __launch_bounds__(WAVE) void adjacency_bits_kernel(MarlEnvParams P, const double* x, const double* y,
+                                                              const int32_t* band, uint32_t* bits) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* A;
+    WaveLds& L = carve(smem, A);
+    const int e = blockIdx.x, lane = threadIdx.x, n = P.N;
+    if (lane < n) { L.sx[lane] = x[(size_t)e * n + lane]; L.sy[lane] = y[(size_t)e * n + lane]; }
+    WSYNC();
+    int b = band[e]; b = b < 0 ? 0 : (b > 3 ? 3 : b);
+    store_bits(bits, e, n, lane, adjacency_row(L, n, lane, P.comm_d2_max[b]));
+}
+
+__global__ __launch_bounds__(WAVE) void jam_bits_kernel(MarlEnvParams P, const double* x, const double* y,
+                                                        const int32_t* band, const double* jx, const double* jy,
+                                                        const int32_t* jb, uint32_t* bits) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* A;
+    WaveLds& L = carve(smem, A);
+    const int e = blockIdx.x, lane = threadIdx.x, n = P.N, m = P.M;
+    if (lane < n) { L.sx[lane] = x[(size_t)e * n + lane]; L.sy[lane] = y[(size_t)e * n + lane]; }
+    if (lane < m) {
+        L.jx[lane] = jx[(size_t)e * m + lane]; L.jy[lane] = jy[(size_t)e * m + lane];
+        L.jb[lane] = jb[(size_t)e * m + lane];
+    }
+    WSYNC();
+    int b = band[e]; b = b < 0 ? 0 : (b > 3 ? 3 : b);
+    store_bits(bits, e, n, lane, jam_row(L, n, m, lane, b, P.jam_d2_max[b]));
+}
+
+__global__ __launch_bounds__(WAVE) void lambda2_bits_kernel(int n, const uint32_t* bits, double* lambda2, int rounds) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* A;
+    WaveLds& L = carve(smem, A);
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int W = (n + 31) / 32;
+    uint64_t row = 0;
+    if (lane < n) {
+        const uint32_t* p = bits + ((size_t)e * n + lane) * W;
+        row = p[0];
+        if (W > 1) row |= (uint64_t)p[1] << 32;
+        row &= ~(1ull << lane);
+        if (n < 64) row &= (1ull << n) - 1;
+    }
+    const double lam = lambda2_wave(row, n, lane, L, A, rounds);
+    if (lane == 0) lambda2[e] = lam;
+}
+
+__global__ __launch_bounds__(WAVE) void dbscan_kernel(MarlEnvParams P, const double* x, const double* y,
+                                                      int32_t* labels, double* cx, double* cy, int32_t* csz,
+                                                      int32_t* n_clusters, int32_t* ncent_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* A;
+    WaveLds& L = carve(smem, A);
+    const int e = blockIdx.x, lane = threadIdx.x, n = P.N, KS = n + 1;
+    if (lane < n) { L.sx[lane] = x[(size_t)e * n + lane]; L.sy[lane] = y[(size_t)e * n + lane]; }
+    WSYNC();
+    int num, ncent;
+    const int label = dbscan_wave(P, n, lane, L, num, ncent);
+    if (lane < n) labels[(size_t)e * n + lane] = label;
+    for (int s = lane; s < ncent; s += WAVE) {
+        cx[(size_t)e * KS + s] = L.cx[s];
+        cy[(size_t)e * KS + s] = L.cy[s];
+        csz[(size_t)e * KS + s] = L.csz[s];
+    }
+    if (lane == 0) { n_clusters[e] = num; ncent_out[e] = ncent; }
+}
+
+// GAE (rollout_buffer.py:151-204): one lane per env, reverse scan over T in float32.
+__global__ void gae_kernel(int T, int E, const float* rewards, const float* values, const float* dones,
+                           const float* last_value, const float* last_done, float gamma, float gamma_lam,
+                           float* adv, float* ret) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const float ld = last_done[e];
+    float next_v = last_value[e] * (1.0f - ld);
+    float next_d = ld;
+    float last = 0.0f;
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t o = (size_t)t * E + e;
+        const float nnt = 1.0f - next_d;
+        const float v = values[o];
+        const float delta = rewards[o] + gamma * next_v * nnt - v;
+        last = delta + gamma_lam * nnt * last;
+        adv[o] = last;
+        ret[o] = last + v;
+        next_v = v;
+        next_d = dones[o];
+    }
+}
+
+__global__ void fill_noise_kernel(MarlEnvParams P, MarlEnvState S, uint64_t seed, uint64_t env_offset, double* noise) {
+    const int e = blockIdx.x, i = threadIdx.x;
+    if (i >= P.N) return;
+    double nx, ny;
+    noise_pair(seed, env_offset + e, (uint32_t)(S.step_count[e] + 1), (uint32_t)i, P.noise_std, nx, ny);
+    noise[((size_t)e * P.N + i) * 2] = nx;
+    noise[((size_t)e * P.N + i) * 2 + 1] = ny;
+}
+
+// ------------------------------------------------------------------ host side
+int hip_check(hipError_t err) {
+    if (err == hipSuccess) return MARL_OK;
+    g_last_hip_error = (int)err;
+    return MARL_EHIP;
+}
+
+// Reference chain of received_power_watts (fspl.py:199-206) applied to a squared distance.
+bool power_reaches(double d2, double P_w, double wavelength, double threshold_w) {
+    double d = sqrt(d2);
+    if (!(d > 1e-10)) d = 1e-10;                       // np.maximum(distance, eps)
+    volatile double t = kFourPi * d;
+    volatile double g = wavelength / t;
+    volatile double pg = g * g;
+    volatile double pr = P_w * pg;
+    return pr >= threshold_w;
+}
+
+// Largest double d2 >= 0 with power_reaches(d2); -1 when even d2 = 0 fails.  The chain
+// is monotone non-increasing in d2 (every operation is correctly rounded), so
+// bisection over the ordered bit patterns of non-negative doubles finds it exactly.
+double largest_reaching_d2(double P_w, double wavelength, double threshold_w) {
+    if (!power_reaches(0.0, P_w, wavelength, threshold_w)) return -1.0;
+    uint64_t lo = 0;                                    // reaches
+    uint64_t hi = 0x7FEFFFFFFFFFFFFFull;                // DBL_MAX
+    double dhi;
+    memcpy(&dhi, &hi, 8);
+    if (power_reaches(dhi, P_w, wavelength, threshold_w)) return dhi;
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        double dm;
+        memcpy(&dm, &mid, 8);
+        if (power_reaches(dm, P_w, wavelength, threshold_w)) lo = mid; else hi = mid;
+    }
+    double out;
+    memcpy(&out, &lo, 8);
+    return out;
+}
+
+int check_sizes(const MarlEnvParams* p) {
+    if (p == nullptr) return MARL_EINVAL;
+    if (p->N < 1 || p->M < 1) return MARL_EINVAL;
+    if (p->N > MARL_MAX_N || p->M > MARL_MAX_M) return MARL_EUNSUPPORTED;
+    return MARL_OK;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+const char* marl_strerror(int code) {
+    switch (code) {
+        case MARL_OK: return "ok";
+        case MARL_EINVAL: return "invalid argument";
+        case MARL_EUNSUPPORTED: return "size not supported by the kernels (N <= 256, M <= 64)";
+        case MARL_EHIP: return "HIP runtime error";
+        default: return "unknown error";
+    }
+}
+
+int marl_last_hip_error(void) { return g_last_hip_error; }
+
+int marl_params_init(MarlEnvParams* p) {
+    int rc = check_sizes(p);
+    if (rc != MARL_OK) return rc;
+    if (!(p->arena_size > 0) || !(p->dt > 0) || p->K_recompute < 1 || p->max_steps < 1) return MARL_EINVAL;
+    for (int b = 0; b < MARL_NUM_BANDS; ++b) {
+        const double wl = kSpeedOfLight / band_hz(b);
+        p->comm_d2_max[b] = largest_reaching_d2(p->P_tx_w, wl, p->P_sens_w);
+        p->jam_d2_max[b] = largest_reaching_d2(p->P_jam_w, wl, p->P_thr_w);
+        volatile double ratio = p->P_jam_w / p->P_thr_w;     // compute_jam_range (fspl.py:306-308)
+        volatile double a = wl / kFourPi;
+        p->R_jam[b] = a * sqrt(ratio);
+    }
+    p->dt_f32 = (float)p->dt;
+    p->v_max_f32 = (float)p->v_max;
+    p->v_max_sq_f32 = (float)(p->v_max * p->v_max);
+    p->pad_f32 = 0.0f;
+    if (p->lambda2_rounds <= 0) p->lambda2_rounds = 7;
+    return MARL_OK;
+}
+
+size_t marl_state_bytes(const MarlEnvParams* p, int32_t E) {
+    if (check_sizes(p) != MARL_OK || E < 1) return 0;
+    const size_t n = p->N, m = p->M, ks = n + 1, e = (size_t)E;
+    size_t b = 0;
+    b += 4 * align256(e * n * 8);        // enemy x, y, vx, vy
+    b += 2 * align256(e * m * 8);        // jam x, y
+    b += align256(e * m * 4);            // jam_band
+    b += 2 * align256(e * m * 4);        // last_vx, last_vy
+    b += 2 * align256(e * 4);            // step_count, enemy_band
+    b += align256(e * 8);                // lambda2_initial
+    b += align256(e * n * 4);            // labels
+    b += 2 * align256(e * ks * 8);       // cent x, y
+    b += align256(e * ks * 4);           // cent_size
+    b += 2 * align256(e * 4);            // n_clusters, ncent
+    b += 2 * align256(e * ks * 8);       // prev x, y
+    b += 2 * align256(e * 4);            // prev_n_clusters, prev_ncent
+    b += align256(e * m * 4);            // assign
+    return b;
+}
+
+int marl_state_bind(MarlEnvState* s, const MarlEnvParams* p, int32_t E, void* base) {
+    if (s == nullptr || base == nullptr || E < 1) return MARL_EINVAL;
+    int rc = check_sizes(p);
+    if (rc != MARL_OK) return rc;
+    if (((uintptr_t)base & 255) != 0) return MARL_EINVAL;
+    const size_t n = p->N, m = p->M, ks = n + 1, e = (size_t)E;
+    unsigned char* c = (unsigned char*)base;
+    auto take = [&](size_t bytes) { void* r = c; c += align256(bytes); return r; };
+    s->E = E; s->pad = 0;
+    s->enemy_x = (double*)take(e * n * 8); s->enemy_y = (double*)take(e * n * 8);
+    s->enemy_vx = (double*)take(e * n * 8); s->enemy_vy = (double*)take(e * n * 8);
+    s->jam_x = (double*)take(e * m * 8); s->jam_y = (double*)take(e * m * 8);
+    s->jam_band = (int32_t*)take(e * m * 4);
+    s->last_vx = (float*)take(e * m * 4); s->last_vy = (float*)take(e * m * 4);
+    s->step_count = (int32_t*)take(e * 4); s->enemy_band = (int32_t*)take(e * 4);
+    s->lambda2_initial = (double*)take(e * 8);
+    s->labels = (int32_t*)take(e * n * 4);
+    s->cent_x = (double*)take(e * ks * 8); s->cent_y = (double*)take(e * ks * 8);
+    s->cent_size = (int32_t*)take(e * ks * 4);
+    s->n_clusters = (int32_t*)take(e * 4); s->ncent = (int32_t*)take(e * 4);
+    s->prev_x = (double*)take(e * ks * 8); s->prev_y = (double*)take(e * ks * 8);
+    s->prev_n_clusters = (int32_t*)take(e * 4); s->prev_ncent = (int32_t*)take(e * 4);
+    s->assign = (int32_t*)take(e * m * 4);
+    return MARL_OK;
+}
+
+int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepIO* io, void* stream) {
+    if (p == nullptr || s == nullptr || io == nullptr) return MARL_EINVAL;
+    int rc = check_sizes(p);
+    if (rc != MARL_OK) return rc;
+    if (s->E < 1 || io->actions == nullptr || io->obs == nullptr || io->reward == nullptr ||
+        io->truncated == nullptr || s->enemy_x == nullptr)
+        return MARL_EINVAL;
+    if (p->N > WAVE) return MARL_EUNSUPPORTED;
+    hipLaunchKernelGGL(env_step_wave_kernel, dim3(s->E), dim3(WAVE), wave_lds_bytes(p->N), (hipStream_t)stream,
+                       *p, *s, *io);
+    return hip_check(hipGetLastError());
+}
+
+int marl_env_reset(const MarlEnvParams* p, const MarlEnvState* s, const MarlResetIO* io, void* stream) {
+    if (p == nullptr || s == nullptr || io == nullptr) return MARL_EINVAL;
+    int rc = check_sizes(p);
+    if (rc != MARL_OK) return rc;
+    if (s->E < 1 || s->enemy_x == nullptr) return MARL_EINVAL;
+    if ((io->enemy_pos == nullptr) != (io->enemy_vel == nullptr)) return MARL_EINVAL;
+    if (p->N > WAVE) return MARL_EUNSUPPORTED;
+    hipLaunchKernelGGL(env_reset_wave_kernel, dim3(s->E), dim3(WAVE), wave_lds_bytes(p->N), (hipStream_t)stream,
+                       *p, *s, *io);
+    return hip_check(hipGetLastError());
+}
+
+int marl_adjacency_bits(const MarlEnvParams* p, int32_t E, const double* x, const double* y, const int32_t* band,
+                        uint32_t* bits, void* stream) {
+    int rc = check_sizes(p);
+    if (rc != MARL_OK) return rc;
+    if (E < 1 || !x || !y || !band || !bits) return MARL_EINVAL;
+    if (p->N > WAVE) return MARL_EUNSUPPORTED;
+    hipLaunchKernelGGL(adjacency_bits_kernel, dim3(E), dim3(WAVE), sizeof(WaveLds), (hipStream_t)stream, *p, x, y,
+                       band, bits);
+    return hip_check(hipGetLastError());
+}
+
+int marl_jam_mask_bits(const MarlEnvParams* p, int32_t E, const double* x, const double* y, const int32_t* band,
+                       const double* jam_x, const double* jam_y, const int32_t* jam_band, uint32_t* bits,
+                       void* stream) {
+    int rc = check_sizes(p);
+    if (rc != MARL_OK) return rc;
+    if (E < 1 || !x || !y || !band || !jam_x || !jam_y || !jam_band || !bits) return MARL_EINVAL;
+    if (p->N > WAVE) return MARL_EUNSUPPORTED;
+    hipLaunchKernelGGL(jam_bits_kernel, dim3(E), dim3(WAVE), sizeof(WaveLds), (hipStream_t)stream, *p, x, y, band,
+                       jam_x, jam_y, jam_band, bits);
+    return hip_check(hipGetLastError());
+}
+
+int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t* bits, double* lambda2, int32_t rounds,
+                           void* stream) {
+    if (N < 1 || E < 1 || !bits || !lambda2) return MARL_EINVAL;
+    if (N > WAVE) return MARL_EUNSUPPORTED;
+    if (rounds <= 0) rounds = 7;
+    hipLaunchKernelGGL(lambda2_bits_kernel, dim3(E), dim3(WAVE), wave_lds_bytes(N), (hipStream_t)stream, (int)N,
+                       bits, lambda2, (int)rounds);
+    return hip_check(hipGetLastError());
+}
+
+int marl_dbscan(const MarlEnvParams* p, int32_t E, const double* x, const double* y, int32_t* labels,
+                double* cent_x, double* cent_y, int32_t* cent_size, int32_t* n_clusters, int32_t* ncent,
+                void* stream) {
+    int rc = check_sizes(p);
+    if (rc != MARL_OK) return rc;
+    if (E < 1 || !x || !y || !labels || !cent_x || !cent_y || !cent_size || !n_clusters || !ncent)
+        return MARL_EINVAL;
+    if (p->N > WAVE) return MARL_EUNSUPPORTED;
+    hipLaunchKernelGGL(dbscan_kernel, dim3(E), dim3(WAVE), sizeof(WaveLds), (hipStream_t)stream, *p, x, y, labels,
+                       cent_x, cent_y, cent_size, n_clusters, ncent);
+    return hip_check(hipGetLastError());
+}
+
+int marl_gae(int32_t T, int32_t E, const float* rewards, const float* values, const float* dones,
+             const float* last_value, const float* last_done, double gamma, double lam, float* advantages,
+             float* returns, void* stream) {
+    if (T < 1 || E < 1 || !rewards || !values || !dones || !last_value || !last_done || !advantages || !returns)
+        return MARL_EINVAL;
+    const int block = 256;
+    hipLaunchKernelGGL(gae_kernel, dim3((E + block - 1) / block), dim3(block), 0, (hipStream_t)stream, (int)T,
+                       (int)E, rewards, values, dones, last_value, last_done, (float)gamma, (float)(gamma * lam), advantages,
+                       returns);
+    return hip_check(hipGetLastError());
+}
+
+int marl_fill_noise(const MarlEnvParams* p, const MarlEnvState* s, uint64_t seed, uint64_t env_offset,
+                    double* noise, void* stream) {
+    int rc = check_sizes(p);
+    if (rc != MARL_OK) return rc;
+    if (!s || s->E < 1 || !noise) return MARL_EINVAL;
+    hipLaunchKernelGGL(fill_noise_kernel, dim3(s->E), dim3(MARL_MAX_N), 0, (hipStream_t)stream, *p, *s, seed,
+                       env_offset, noise);
+    return hip_check(hipGetLastError());
+}
+
+}  // extern "C"

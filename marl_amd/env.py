@@ -1,0 +1,475 @@
+"""Host side of the batched JammerEnv step.
+
+`BatchedJammerEnv` advances E environments in lockstep on one GPU: all state is
+device resident (one caller-owned buffer carved by `marl_state_bind`), `step`
+and `reset` each launch one HIP kernel of libmarl_env.so on torch's current
+stream and return device tensors without synchronising.
+
+`JammerEnv` is the single-environment facade with the reference's constructor,
+`reset()` / `step()` tuples, `info` keys and attributes
+(reference: environment/jammer_env.py:94-127, 261-354, 356-457).  It draws the
+random numbers on the host from numpy `RandomState` streams in the order the
+reference consumes them, so a seed gives the same trajectory as the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MarlEnvParams, MarlEnvState, MarlResetIO, MarlStepIO
+
+BANDS = [433e6, 915e6, 2.4e9, 5.8e9]          # jammer_env.py:182
+
+
+def db_to_watts(dbm: float) -> float:
+    """physics/fspl.py:50-69"""
+    return 10 ** ((dbm - 30) / 10)
+
+
+@dataclass
+class EnvConfig:
+    """Constructor arguments of the reference JammerEnv (jammer_env.py:94-127)."""
+    M: int = 4
+    N: int = 20
+    arena_size: float = 200.0
+    max_steps: int = 200
+    dt: float = 0.5
+    v_max: float = 5.0
+    v_enemy: float = 2.0
+    enemy_mode: str = "random_walk"
+    P_tx_dbm: float = 20.0
+    P_sens_dbm: float = -90.0
+    P_jammer_dbm: float = 30.0
+    P_jam_thresh_dbm: float = -70.0
+    omega_1: float = 1.0
+    omega_2: float = 0.3
+    omega_3: float = 0.2
+    omega_4: float = 0.1
+    omega_5: float = 0.2
+    eps: float = 30.0
+    min_samples: int = 2
+    K_recompute: int = 10
+    min_lambda2_initial: float = 0.5
+    max_reset_attempts: int = 100
+    random_jammer_start: bool = False
+    lambda2_rounds: int = 0
+
+    @staticmethod
+    def fast_preset(N: int = 10, M: int = 4, **kw) -> "EnvConfig":
+        """Environment of the reference's `fast` preset (training/config.py:258-272)."""
+        base = dict(M=M, N=N, arena_size=200.0, max_steps=200, P_jammer_dbm=20.0, P_jam_thresh_dbm=-40.0,
+                    eps=25.0, min_samples=2, K_recompute=10, random_jammer_start=True)
+        base.update(kw)
+        return EnvConfig(**base)
+
+    def to_params(self) -> MarlEnvParams:
+        if self.enemy_mode != "random_walk":
+            raise NotImplementedError("only the random_walk enemy model (enemy_swarm.py:157-189) runs on the GPU")
+        p = MarlEnvParams()
+        p.N, p.M = int(self.N), int(self.M)
+        p.max_steps, p.K_recompute, p.min_samples = int(self.max_steps), int(self.K_recompute), int(self.min_samples)
+        p.random_jammer_start = int(bool(self.random_jammer_start))
+        p.max_reset_attempts = int(self.max_reset_attempts)
+        p.lambda2_rounds = int(self.lambda2_rounds)
+        p.arena_size, p.dt, p.v_max, p.v_enemy = float(self.arena_size), float(self.dt), float(self.v_max), float(self.v_enemy)
+        p.P_tx_w, p.P_sens_w = db_to_watts(self.P_tx_dbm), db_to_watts(self.P_sens_dbm)
+        p.P_jam_w, p.P_thr_w = db_to_watts(self.P_jammer_dbm), db_to_watts(self.P_jam_thresh_dbm)
+        for i, w in enumerate((self.omega_1, self.omega_2, self.omega_3, self.omega_4, self.omega_5)):
+            p.omega[i] = float(w)
+        p.kappa, p.eps = 0.05, float(self.eps)
+        p.drift_threshold, p.spread, p.noise_std = 30.0, 10.0, 0.1
+        p.min_lambda2_initial = float(self.min_lambda2_initial)
+        _lib.check(_lib.load().marl_params_init(C.byref(p)), "marl_params_init")
+        return p
+
+
+_DT = {"f64": torch.float64, "f32": torch.float32, "i32": torch.int32}
+_STATE_SPEC = {   # name -> (dtype, shape as function of (E, N, M))
+    "enemy_x": ("f64", "EN"), "enemy_y": ("f64", "EN"), "enemy_vx": ("f64", "EN"), "enemy_vy": ("f64", "EN"),
+    "jam_x": ("f64", "EM"), "jam_y": ("f64", "EM"), "jam_band": ("i32", "EM"),
+    "last_vx": ("f32", "EM"), "last_vy": ("f32", "EM"),
+    "step_count": ("i32", "E"), "enemy_band": ("i32", "E"), "lambda2_initial": ("f64", "E"),
+    "labels": ("i32", "EN"), "cent_x": ("f64", "EK"), "cent_y": ("f64", "EK"), "cent_size": ("i32", "EK"),
+    "n_clusters": ("i32", "E"), "ncent": ("i32", "E"), "prev_x": ("f64", "EK"), "prev_y": ("f64", "EK"),
+    "prev_n_clusters": ("i32", "E"), "prev_ncent": ("i32", "E"), "assign": ("i32", "EM"),
+}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class BatchedJammerEnv:
+    """E reference environments advanced in lockstep on one GPU.
+
+    step(actions) -> (obs, reward, terminated, truncated, info), all device
+    tensors of leading dimension E.  With `auto_reset=True` an env whose episode
+    was truncated is reset inside the same call and `obs` holds its first
+    observation of the next episode, as the reference trainer does
+    (training/trainer.py:248-278); the terminal-step metrics stay in `info`
+    (`lambda2_current`, `episode_lambda2_initial`).
+    """
+
+    def __init__(self, num_envs: int, config: Optional[EnvConfig] = None, seed: int = 0, device="cuda",
+                 auto_reset: bool = True, env_offset: int = 0, track_avg_power: bool = False,
+                 debug_bits: bool = False, **cfg_kwargs):
+        self.cfg = config if config is not None else EnvConfig(**cfg_kwargs)
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.MarlError("BatchedJammerEnv needs a HIP device; there is no CPU implementation")
+        self.device = torch.device(device)
+        self.E, self.N, self.M = int(num_envs), self.cfg.N, self.cfg.M
+        self.seed, self.env_offset, self.auto_reset = int(seed), int(env_offset), auto_reset
+        self.params = self.cfg.to_params()
+        nbytes = self.lib.marl_state_bytes(C.byref(self.params), self.E)
+        if nbytes == 0:
+            raise _lib.MarlError("marl_state_bytes: unsupported sizes")
+        with torch.cuda.device(self.device):
+            self._buf = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
+            base = (self._buf.data_ptr() + 255) & ~255
+            self.state = MarlEnvState()
+            _lib.check(self.lib.marl_state_bind(C.byref(self.state), C.byref(self.params), self.E,
+                                                C.c_void_p(base)), "marl_state_bind")
+            dims = {"E": (self.E,), "EN": (self.E, self.N), "EM": (self.E, self.M), "EK": (self.E, self.N + 1)}
+            self.views: Dict[str, torch.Tensor] = {}
+            for name, (dt, shp) in _STATE_SPEC.items():
+                off = getattr(self.state, name) - self._buf.data_ptr()
+                shape = dims[shp]
+                dtype = _DT[dt]
+                nb = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+                self.views[name] = self._buf[off:off + nb].view(dtype).view(shape)
+            self.obs = torch.zeros(self.E, self.M, 5, dtype=torch.float32, device=self.device)
+            self.reward = torch.zeros(self.E, dtype=torch.float32, device=self.device)
+            self._trunc_u8 = torch.zeros(self.E, dtype=torch.uint8, device=self.device)
+            self.lambda2 = torch.zeros(self.E, dtype=torch.float64, device=self.device)
+            self.reward_terms = torch.zeros(self.E, 5, dtype=torch.float32, device=self.device)
+            self.avg_power = torch.zeros(self.E, dtype=torch.float64, device=self.device) if track_avg_power else None
+            W = (self.N + 31) // 32
+            self.adj_bits = torch.zeros(self.E, self.N, W, dtype=torch.int32, device=self.device) if debug_bits else None
+            self.jam_bits = torch.zeros(self.E, self.N, W, dtype=torch.int32, device=self.device) if debug_bits else None
+            self._terminated = torch.zeros(self.E, dtype=torch.bool, device=self.device)
+        self._episode = 0
+
+    # -- reset ---------------------------------------------------------------
+    def reset(self, seed: Optional[int] = None, mask: Optional[torch.Tensor] = None, *,
+              enemy_pos=None, enemy_vel=None, enemy_band=None, jam_init=None, jam_band=None,
+              out_obs: Optional[torch.Tensor] = None):
+        """JammerEnv.reset for the masked envs (all when mask is None).  The
+        keyword tensors override the on-device random draws (enemy_pos/enemy_vel
+        [E,N,2] f64, enemy_band [E] i32, jam_init [E,M,2] f64, jam_band [E,M] i32)."""
+        if seed is not None:
+            self.seed = int(seed)
+            self._episode = 0
+        io = MarlResetIO()
+        keep = []
+
+        def dev(t, dtype):
+            if t is None:
+                return None
+            t = torch.as_tensor(t, dtype=dtype, device=self.device).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        if mask is not None:
+            io.mask = dev(mask.to(torch.uint8) if isinstance(mask, torch.Tensor) else np.asarray(mask, np.uint8), torch.uint8)
+        io.enemy_pos = dev(enemy_pos, torch.float64)
+        io.enemy_vel = dev(enemy_vel, torch.float64)
+        io.enemy_band = dev(enemy_band, torch.int32)
+        io.jam_init = dev(jam_init, torch.float64)
+        io.jam_band = dev(jam_band, torch.int32)
+        obs = self.obs if out_obs is None else out_obs
+        io.obs = obs.data_ptr()
+        io.seed, io.episode, io.env_offset = self.seed, self._episode, self.env_offset
+        self._episode += 1
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.marl_env_reset(C.byref(self.params), C.byref(self.state), C.byref(io), _stream()),
+                       "marl_env_reset")
+        self._keepalive = keep
+        v = self.views
+        info = dict(lambda2_initial=v["lambda2_initial"], lambda2_current=v["lambda2_initial"],
+                    enemy_band=v["enemy_band"], n_clusters=v["n_clusters"], step=v["step_count"])
+        return obs, info
+
+    # -- step ----------------------------------------------------------------
+    def step(self, actions: torch.Tensor, noise: Optional[torch.Tensor] = None, *,
+             out_obs: Optional[torch.Tensor] = None, out_reward: Optional[torch.Tensor] = None,
+             out_truncated: Optional[torch.Tensor] = None):
+        """One JammerEnv.step per env.  `actions` [E,M,3] float32 on the device.
+        `noise` [E,N,2] float64 replaces the on-device enemy noise generator.
+        out_* let the caller have results written straight into its own storage
+        (e.g. slot t of a rollout buffer)."""
+        if actions.dtype != torch.float32 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(actions.shape) != (self.E, self.M, 3):
+            raise ValueError(f"actions must be [{self.E},{self.M},3], got {tuple(actions.shape)}")
+        if noise is not None:
+            noise = noise.to(device=self.device, dtype=torch.float64).contiguous()
+            if tuple(noise.shape) != (self.E, self.N, 2):
+                raise ValueError(f"noise must be [{self.E},{self.N},2]")
+        obs = self.obs if out_obs is None else out_obs
+        reward = self.reward if out_reward is None else out_reward
+        trunc = self._trunc_u8 if out_truncated is None else out_truncated
+        io = MarlStepIO()
+        io.actions, io.noise = actions.data_ptr(), _ptr(noise)
+        io.obs, io.reward, io.truncated = obs.data_ptr(), reward.data_ptr(), trunc.data_ptr()
+        io.lambda2, io.reward_terms = self.lambda2.data_ptr(), self.reward_terms.data_ptr()
+        io.avg_power_dbm = _ptr(self.avg_power)
+        io.adj_bits, io.jam_bits = _ptr(self.adj_bits), _ptr(self.jam_bits)
+        io.seed, io.env_offset = self.seed, self.env_offset
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.marl_env_step(C.byref(self.params), C.byref(self.state), C.byref(io), _stream()),
+                       "marl_env_step")
+        v = self.views
+        info: Dict[str, Any] = dict(lambda2_current=self.lambda2, lambda2_initial=v["lambda2_initial"],
+                                    enemy_band=v["enemy_band"], n_clusters=v["n_clusters"],
+                                    step=v["step_count"], reward_terms=self.reward_terms)
+        if self.avg_power is not None:
+            info["avg_jamming_power_dbm"] = self.avg_power
+        truncated = trunc.view(torch.bool) if trunc.dtype == torch.uint8 else trunc
+        if self.auto_reset:
+            info["episode_lambda2_initial"] = v["lambda2_initial"].clone()
+            info["episode_step"] = v["step_count"].clone()
+            rio = MarlResetIO()
+            rio.mask = trunc.data_ptr()
+            rio.obs = obs.data_ptr()
+            rio.seed, rio.episode, rio.env_offset = self.seed, self._episode, self.env_offset
+            self._episode += 1
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.marl_env_reset(C.byref(self.params), C.byref(self.state), C.byref(rio),
+                                                   _stream()), "marl_env_reset")
+        return obs, reward, self._terminated, truncated, info
+
+    def fill_noise(self) -> torch.Tensor:
+        """The enemy noise the next step() draws when called with noise=None."""
+        out = torch.empty(self.E, self.N, 2, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.marl_fill_noise(C.byref(self.params), C.byref(self.state), self.seed,
+                                                self.env_offset, out.data_ptr(), _stream()), "marl_fill_noise")
+        return out
+
+    def state_numpy(self, e: int = 0) -> Dict[str, np.ndarray]:
+        return {k: v[e].cpu().numpy() for k, v in self.views.items()}
+
+
+# ---------------------------------------------------------------------------
+# single-env facade with the reference's API
+# ---------------------------------------------------------------------------
+class _Box:
+    def __init__(self, low, high, shape, dtype):
+        self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+
+class _SwarmView:
+    """`env.enemy_swarm.positions / .velocities` of the reference (enemy_swarm.py:96-110)."""
+
+    def __init__(self, env: "JammerEnv"):
+        self._env = env
+        self._rng = np.random.RandomState()
+
+    @property
+    def positions(self) -> np.ndarray:
+        v = self._env._b.views
+        return np.stack([v["enemy_x"][0].cpu().numpy(), v["enemy_y"][0].cpu().numpy()], axis=1)
+
+    @property
+    def velocities(self) -> np.ndarray:
+        v = self._env._b.views
+        return np.stack([v["enemy_vx"][0].cpu().numpy(), v["enemy_vy"][0].cpu().numpy()], axis=1)
+
+
+class _ClustererView:
+    def __init__(self, env: "JammerEnv"):
+        self._env = env
+
+    @property
+    def n_clusters(self) -> int:
+        return int(self._env._b.views["n_clusters"][0].item())
+
+    @property
+    def labels(self) -> np.ndarray:
+        return self._env._b.views["labels"][0].cpu().numpy().astype(np.int64)
+
+
+class JammerEnv:
+    """Drop-in for the reference `JammerEnv` (environment/jammer_env.py:59): same
+    constructor, same `reset(seed, options)` / `step(action)` return tuples and
+    `info` keys.  One environment = a batch of one on the GPU."""
+
+    metadata = {"render_modes": ["human", "rgb_array"]}
+
+    def __init__(self, M=4, N=20, arena_size=200.0, max_steps=200, dt=0.5, v_max=5.0, v_enemy=2.0,
+                 enemy_mode="random_walk", P_tx_dbm=20.0, P_sens_dbm=-90.0, P_jammer_dbm=30.0,
+                 P_jam_thresh_dbm=-70.0, omega_1=1.0, omega_2=0.3, omega_3=0.2, omega_4=0.1, omega_5=0.2,
+                 eps=30.0, min_samples=2, K_recompute=10, min_lambda2_initial=0.5, max_reset_attempts=100,
+                 debug_mode=False, random_jammer_start=False, seed=None, render_mode=None, device="cuda"):
+        self.cfg = EnvConfig(M=M, N=N, arena_size=arena_size, max_steps=max_steps, dt=dt, v_max=v_max,
+                             v_enemy=v_enemy, enemy_mode=enemy_mode, P_tx_dbm=P_tx_dbm, P_sens_dbm=P_sens_dbm,
+                             P_jammer_dbm=P_jammer_dbm, P_jam_thresh_dbm=P_jam_thresh_dbm, omega_1=omega_1,
+                             omega_2=omega_2, omega_3=omega_3, omega_4=omega_4, omega_5=omega_5, eps=eps,
+                             min_samples=min_samples, K_recompute=K_recompute,
+                             min_lambda2_initial=min_lambda2_initial, max_reset_attempts=max_reset_attempts,
+                             random_jammer_start=random_jammer_start)
+        self.M, self.N, self.arena_size, self.max_steps = M, N, arena_size, max_steps
+        self.dt, self.v_max, self.v_enemy, self.enemy_mode = dt, v_max, v_enemy, enemy_mode
+        self.P_tx_dbm, self.P_sens_dbm = P_tx_dbm, P_sens_dbm
+        self.P_jammer_dbm, self.P_jam_thresh_dbm = P_jammer_dbm, P_jam_thresh_dbm
+        self.eps, self.min_samples, self.K_recompute = eps, min_samples, K_recompute
+        self.min_lambda2_initial, self.max_reset_attempts = min_lambda2_initial, max_reset_attempts
+        self.debug_mode, self.random_jammer_start, self.render_mode = debug_mode, random_jammer_start, render_mode
+        self.BANDS = list(BANDS)
+        self.num_bands = len(self.BANDS)
+        self._b = BatchedJammerEnv(1, self.cfg, device=device, auto_reset=False, track_avg_power=True)
+        self.R_jam = float(self._b.params.R_jam[2])             # default band 2.4 GHz (jammer_env.py:187-189)
+        self.observation_space = _Box(0.0, 1.0, (M, 5), np.float32)
+        self.action_space = {"velocity": _Box(-v_max, v_max, (M, 2), np.float32), "band": [self.num_bands] * M}
+        # RNG streams of the reference: EnemySwarm.__init__ seeds the global numpy
+        # generator and its own RandomState (enemy_swarm.py:87-91); the env has a
+        # second RandomState (jammer_env.py:250).
+        self.enemy_swarm = _SwarmView(self)
+        if seed is not None:
+            np.random.seed(seed)
+            self.enemy_swarm._rng = np.random.RandomState(seed)
+        # constructor draws of EnemySwarm (positions, headings) advance its stream
+        self.enemy_swarm._rng.uniform(arena_size * 0.1, arena_size - arena_size * 0.1, size=(N, 2))
+        self.enemy_swarm._rng.uniform(0, 2 * np.pi, size=N)
+        self.clusterer = _ClustererView(self)
+        self._rng = np.random.RandomState(seed)
+        self.enemy_band = 2
+        self.lambda2_initial = 0.0
+
+    # -- attributes the reference exposes -------------------------------------
+    @property
+    def step_count(self) -> int:
+        return int(self._b.views["step_count"][0].item())
+
+    @property
+    def jammer_positions(self) -> np.ndarray:
+        v = self._b.views
+        return np.stack([v["jam_x"][0].cpu().numpy(), v["jam_y"][0].cpu().numpy()], axis=1)
+
+    @jammer_positions.setter
+    def jammer_positions(self, value):
+        value = np.asarray(value, dtype=np.float64)
+        v = self._b.views
+        v["jam_x"][0].copy_(torch.from_numpy(np.ascontiguousarray(value[:, 0])))
+        v["jam_y"][0].copy_(torch.from_numpy(np.ascontiguousarray(value[:, 1])))
+
+    @property
+    def jammer_bands(self) -> np.ndarray:
+        return self._b.views["jam_band"][0].cpu().numpy().astype(np.int32)
+
+    @jammer_bands.setter
+    def jammer_bands(self, value):
+        self._b.views["jam_band"][0].copy_(torch.from_numpy(np.asarray(value, dtype=np.int32)))
+
+    @property
+    def last_velocities(self) -> np.ndarray:
+        v = self._b.views
+        return np.stack([v["last_vx"][0].cpu().numpy(), v["last_vy"][0].cpu().numpy()], axis=1)
+
+    # -- reset (jammer_env.py:261-354) ------------------------------------------
+    def reset(self, seed: Optional[int] = None, options: Optional[Dict[str, Any]] = None):
+        if seed is not None:
+            self._rng = np.random.RandomState(seed)
+        A, N, M = self.arena_size, self.N, self.M
+        reset_seed = seed
+        srng = self.enemy_swarm
+        obs = None
+        for attempt in range(self.max_reset_attempts):
+            if reset_seed is not None:                                    # enemy_swarm.py:259-260
+                srng._rng = np.random.RandomState(reset_seed)
+            margin = A * 0.1
+            epos = srng._rng.uniform(margin, A - margin, size=(N, 2))     # enemy_swarm.py:266-270
+            ang = srng._rng.uniform(0, 2 * np.pi, size=N)
+            evel = np.column_stack([self.v_enemy * np.cos(ang), self.v_enemy * np.sin(ang)])
+            self.enemy_band = int(self._rng.randint(0, self.num_bands))   # jammer_env.py:287
+            # One attempt of the reference's loop = one fit + lambda2_initial.  The jammer draws
+            # are only consumed after the loop ends, so probe with placeholder jammers; the
+            # cluster tables are then put back so that the final call below redoes the last
+            # attempt's fit from the same "previous centroids" the reference would have.
+            last = attempt == self.max_reset_attempts - 1
+            ok = self._probe_reset(epos, evel, restore_always=last)
+            if ok:
+                break
+            reset_seed = None if seed is None else seed + attempt + 1
+        self.R_jam = float(self._b.params.R_jam[self.enemy_band])
+        if self.random_jammer_start:
+            jinit = self._rng.uniform(0.1 * A, 0.9 * A, size=(M, 2))      # jammer_env.py:324-326
+        else:
+            jinit = np.array([np.random.uniform(-10.0, 10.0, size=2) for _ in range(M)])  # dbscan_clustering.py:399
+        jb = self._rng.randint(0, self.num_bands, size=M).astype(np.int32)  # jammer_env.py:339
+        obs_t, _ = self._b.reset(enemy_pos=epos[None], enemy_vel=evel[None],
+                                 enemy_band=np.array([self.enemy_band], np.int32),
+                                 jam_init=jinit[None], jam_band=jb[None])
+        torch.cuda.synchronize()
+        self.lambda2_initial = float(self._b.views["lambda2_initial"][0].item())
+        obs = obs_t[0].cpu().numpy()
+        info = {"lambda2_initial": self.lambda2_initial, "lambda2_current": self.lambda2_initial,
+                "enemy_band": self.enemy_band, "n_clusters": self.clusterer.n_clusters, "step": 0}
+        return obs, info
+
+    def _probe_reset(self, epos, evel, restore_always: bool) -> bool:
+        """Cluster + lambda2_initial for these enemy draws; True when the reference's loop would break."""
+        v = self._b.views
+        names = ("cent_x", "cent_y", "cent_size", "n_clusters", "ncent",
+                 "prev_x", "prev_y", "prev_n_clusters", "prev_ncent")
+        saved = {k: v[k].clone() for k in names}
+        self._b.reset(enemy_pos=epos[None], enemy_vel=evel[None],
+                      enemy_band=np.array([self.enemy_band], np.int32),
+                      jam_init=np.zeros((1, self.M, 2)), jam_band=np.zeros((1, self.M), np.int32))
+        ok = float(v["lambda2_initial"][0].item()) >= self.min_lambda2_initial
+        if ok or restore_always:
+            for k, t in saved.items():
+                v[k].copy_(t)
+        return ok
+
+    # -- step (jammer_env.py:356-457) -------------------------------------------
+    def step(self, action):
+        if isinstance(action, dict):
+            velocity = np.asarray(action["velocity"])
+            bands = np.asarray(action["band"])
+            a = np.zeros((self.M, 3), dtype=np.float32)
+            a[:, :2] = velocity
+            a[:, 2] = bands
+        else:
+            a = np.asarray(action, dtype=np.float32)
+        noise = self.enemy_swarm._rng.normal(0, 0.1, size=(self.N, 2))    # enemy_swarm.py:165
+        act_t = torch.from_numpy(np.ascontiguousarray(a[None])).to(self._b.device)
+        noise_t = torch.from_numpy(noise[None]).to(self._b.device)
+        obs_t, rew_t, _, trunc_t, info_t = self._b.step(act_t, noise_t)
+        torch.cuda.synchronize()
+        lam = float(info_t["lambda2_current"][0].item())
+        lam0 = self.lambda2_initial
+        raw_reduction = 1.0 - (lam / lam0) if lam0 > 1e-6 else 0.0
+        terms = info_t["reward_terms"][0].cpu().numpy().astype(np.float64)
+        c = self.cfg
+        reward = float(rew_t[0].item())
+        breakdown = {"lambda2_reduction": c.omega_1 * terms[0], "band_match": c.omega_2 * terms[1],
+                     "proximity": c.omega_3 * terms[2], "energy_penalty": -c.omega_4 * terms[3],
+                     "overlap_penalty": -c.omega_5 * terms[4], "total": reward}   # reward.py:398-414
+        info = {"lambda2_initial": lam0, "lambda2_current": lam, "lambda2_reduction": raw_reduction,
+                "lambda2_reduction_raw": raw_reduction, "enemy_band": self.enemy_band,
+                "n_clusters": self.clusterer.n_clusters, "step": self.step_count,
+                "reward_components": breakdown, "jammer_positions": self.jammer_positions,
+                "enemy_positions": self.enemy_swarm.positions,
+                "avg_jamming_power_dbm": float(info_t["avg_jamming_power_dbm"][0].item())}
+        return obs_t[0].cpu().numpy(), reward, False, bool(trunc_t[0].item()), info
+
+    def get_global_observation(self) -> np.ndarray:
+        """Mean-pooled observation for the critic (observation.py:335-350)."""
+        return self._b.obs[0].mean(dim=0).cpu().numpy().astype(np.float32)
+
+    def render(self):
+        return None
+
+    def close(self):
+        pass

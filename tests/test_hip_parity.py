@@ -1,0 +1,491 @@
+"""Parity of the HIP path (through the C ABI) with the reference: golden vectors
+produced by the reference itself, and the CPU oracle on seeded random inputs.
+
+Bars: adjacency / jamming bits, DBSCAN labels, sizes, assignments, enemy and
+jammer positions (float64 state): bit-exact.  lambda2: |d| <= 1e-5*max(|l2|,1)
+(the reference returns +-1e-15 noise for disconnected graphs).  Rewards and
+observations: 1e-5 relative (float32 outputs)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from marl_amd import BatchedJammerEnv, EnvConfig, JammerEnv, _lib
+from oracle import jammer_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+MAXN = 64   # sizes the wave-per-env kernels cover
+
+
+def cfg_from(p: orc.EnvParams, **kw) -> EnvConfig:
+    return EnvConfig(M=p.M, N=p.N, arena_size=p.arena_size, max_steps=p.max_steps, dt=p.dt, v_max=p.v_max,
+                     v_enemy=p.v_enemy, P_tx_dbm=p.P_tx_dbm, P_sens_dbm=p.P_sens_dbm,
+                     P_jammer_dbm=p.P_jammer_dbm, P_jam_thresh_dbm=p.P_jam_thresh_dbm, eps=p.eps,
+                     min_samples=p.min_samples, K_recompute=p.K_recompute,
+                     random_jammer_start=p.random_jammer_start, **kw)
+
+
+def dev(a, dtype):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+def bits_np(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def lam_ok(a, b):
+    return abs(a - b) <= 1e-5 * max(abs(b), 1.0)
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---------------------------------------------------------------- stage ops vs reference vectors
+def _stage_groups():
+    groups = {}
+    for p, d in gu.stage_cases():
+        key = (p.N, p.M, p.arena_size, p.P_tx_dbm, p.P_sens_dbm, p.P_jammer_dbm, p.P_jam_thresh_dbm, p.eps,
+               p.min_samples)
+        groups.setdefault(key, (p, []))[1].append(d)
+    return list(groups.values())
+
+
+@pytest.mark.parametrize("gi", range(len(_stage_groups())))
+def test_stage_ops_match_reference_vectors(gi):
+    p, cases = _stage_groups()[gi]
+    if p.N > MAXN:
+        pytest.skip("N > 64 runs on the workgroup-per-env kernels")
+    lib = _lib.load()
+    P = cfg_from(p).to_params()
+    E, N, M = len(cases), p.N, p.M
+    W = (N + 31) // 32
+    x = dev(np.stack([c["epos"][:, 0] for c in cases]), torch.float64)
+    y = dev(np.stack([c["epos"][:, 1] for c in cases]), torch.float64)
+    band = dev(np.array([int(c["band"]) for c in cases]), torch.int32)
+    jx = dev(np.stack([c["jpos"][:, 0] for c in cases]), torch.float64)
+    jy = dev(np.stack([c["jpos"][:, 1] for c in cases]), torch.float64)
+    jb = dev(np.stack([c["jb"] for c in cases]), torch.int32)
+    adj = torch.zeros(E, N, W, dtype=torch.int32, device="cuda")
+    jam = torch.zeros(E, N, W, dtype=torch.int32, device="cuda")
+    _lib.check(lib.marl_adjacency_bits(C.byref(P), E, x.data_ptr(), y.data_ptr(), band.data_ptr(),
+                                       adj.data_ptr(), stream()))
+    _lib.check(lib.marl_jam_mask_bits(C.byref(P), E, x.data_ptr(), y.data_ptr(), band.data_ptr(), jx.data_ptr(),
+                                      jy.data_ptr(), jb.data_ptr(), jam.data_ptr(), stream()))
+    eff = adj & ~jam
+    lam = torch.zeros(E, dtype=torch.float64, device="cuda")
+    lam0 = torch.zeros(E, dtype=torch.float64, device="cuda")
+    _lib.check(lib.marl_lambda2_from_bits(N, E, eff.data_ptr(), lam.data_ptr(), 0, stream()))
+    _lib.check(lib.marl_lambda2_from_bits(N, E, adj.data_ptr(), lam0.data_ptr(), 0, stream()))
+    labels = torch.zeros(E, N, dtype=torch.int32, device="cuda")
+    cx = torch.zeros(E, N + 1, dtype=torch.float64, device="cuda")
+    cy = torch.zeros(E, N + 1, dtype=torch.float64, device="cuda")
+    csz = torch.zeros(E, N + 1, dtype=torch.int32, device="cuda")
+    ncl = torch.zeros(E, dtype=torch.int32, device="cuda")
+    ncent = torch.zeros(E, dtype=torch.int32, device="cuda")
+    _lib.check(lib.marl_dbscan(C.byref(P), E, x.data_ptr(), y.data_ptr(), labels.data_ptr(), cx.data_ptr(),
+                               cy.data_ptr(), csz.data_ptr(), ncl.data_ptr(), ncent.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    for e, c in enumerate(cases):
+        assert np.array_equal(bits_np(adj[e]), c["adj"]), e
+        assert np.array_equal(bits_np(jam[e]), c["jam"]), e
+        assert lam_ok(float(lam[e]), float(c["lam"])), (e, float(lam[e]), float(c["lam"]))
+        assert lam_ok(float(lam0[e]), float(c["lam0"]))
+        assert np.array_equal(labels[e].cpu().numpy(), c["labels"]), e
+        nc = int(c["ncent"])
+        assert int(ncent[e]) == nc and int(ncl[e]) == int(c["n_clusters"])
+        assert np.array_equal(cx[e, :nc].cpu().numpy(), c["cent_xy"][:nc, 0])
+        assert np.array_equal(cy[e, :nc].cpu().numpy(), c["cent_xy"][:nc, 1])
+        assert np.array_equal(csz[e, :nc].cpu().numpy(), c["cent_size"][:nc])
+
+
+def test_lambda2_closed_forms_and_random_graphs():
+    """K_n -> n, path, cycle, disconnected (reference tests/test_laplacian.py:251-310)
+    and random graphs of every density against the reference's eigh values."""
+    lib = _lib.load()
+    z = gu.load("edges.npz")
+    todo = []
+    for n in (2, 3, 4, 5, 6, 10, 50):
+        todo.append((~np.eye(n, dtype=bool), float(n)))
+    for n in (5, 10, 50):
+        A = np.zeros((n, n), dtype=bool)
+        for i in range(n - 1):
+            A[i, i + 1] = A[i + 1, i] = True
+        todo.append((A.copy(), 2 * (1 - math.cos(math.pi / n))))
+        A[0, n - 1] = A[n - 1, 0] = True
+        todo.append((A.copy(), 2 * (1 - math.cos(2 * math.pi / n))))
+    A = np.zeros((6, 6), dtype=bool)
+    for i, j in ((0, 1), (1, 2), (3, 4), (4, 5)):
+        A[i, j] = A[j, i] = True
+    todo.append((A, 0.0))
+    for k in range(int(z["n_graphs"])):
+        n = int(z[f"g{k}_n"])
+        if n <= MAXN:
+            todo.append((orc.unpack_rows(z[f"g{k}_adj"], n), float(z[f"g{k}_lam"])))
+    for A, want in todo:
+        n = A.shape[0]
+        bits = dev(orc.pack_rows(A).view(np.int32)[None], torch.int32)
+        out = torch.zeros(1, dtype=torch.float64, device="cuda")
+        _lib.check(lib.marl_lambda2_from_bits(n, 1, bits.data_ptr(), out.data_ptr(), 0, stream()))
+        got = float(out[0])
+        assert abs(got - want) <= 1e-6 * max(1.0, abs(want)), (n, got, want)
+
+
+def test_lambda2_accuracy_with_more_rounds():
+    """With 9 multisection rounds the eigenvalue agrees with LAPACK to ~1e-11."""
+    lib = _lib.load()
+    rng = np.random.RandomState(3)
+    n, E = 50, 64
+    mats, want = [], []
+    for e in range(E):
+        A = np.triu(rng.rand(n, n) < rng.uniform(0.05, 0.95), 1)
+        A = A | A.T
+        mats.append(orc.pack_rows(A).view(np.int32))
+        want.append(orc.lambda2_of_laplacian(orc.laplacian(A)))
+    bits = dev(np.stack(mats), torch.int32)
+    out = torch.zeros(E, dtype=torch.float64, device="cuda")
+    _lib.check(lib.marl_lambda2_from_bits(n, E, bits.data_ptr(), out.data_ptr(), 9, stream()))
+    got = out.cpu().numpy()
+    assert np.max(np.abs(got - np.array(want))) < 1e-9
+
+
+def test_dbscan_edge_vectors():
+    lib = _lib.load()
+    z = gu.load("edges.npz")
+    for name in z["db_names"]:
+        pts = z[f"db_{name}_pts"]
+        eps, ms = z[f"db_{name}_par"]
+        n = len(pts)
+        P = EnvConfig(N=n, M=2, eps=float(eps), min_samples=int(ms), arena_size=200.0).to_params()
+        x, y = dev(pts[None, :, 0], torch.float64), dev(pts[None, :, 1], torch.float64)
+        labels = torch.zeros(1, n, dtype=torch.int32, device="cuda")
+        cx = torch.zeros(1, n + 1, dtype=torch.float64, device="cuda")
+        cy = torch.zeros_like(cx)
+        csz = torch.zeros(1, n + 1, dtype=torch.int32, device="cuda")
+        ncl = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ncent = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.check(lib.marl_dbscan(C.byref(P), 1, x.data_ptr(), y.data_ptr(), labels.data_ptr(), cx.data_ptr(),
+                                   cy.data_ptr(), csz.data_ptr(), ncl.data_ptr(), ncent.data_ptr(), stream()))
+        nc = int(z[f"db_{name}_ncent"])
+        assert np.array_equal(labels[0].cpu().numpy(), z[f"db_{name}_labels"]), name
+        assert int(ncent[0]) == nc, name
+        assert np.array_equal(cx[0, :nc].cpu().numpy(), z[f"db_{name}_xy"][:nc, 0]), name
+        assert np.array_equal(cy[0, :nc].cpu().numpy(), z[f"db_{name}_xy"][:nc, 1]), name
+        assert np.array_equal(csz[0, :nc].cpu().numpy(), z[f"db_{name}_size"][:nc]), name
+
+
+def test_knife_edge_thresholds():
+    """Pairs within a few ulp of the comm radius / jam radius."""
+    lib = _lib.load()
+    z = gu.load("edges.npz")
+    pos = z["knife_pos"]
+    n = len(pos)
+    P = EnvConfig(N=n, M=1, P_jammer_dbm=20.0, P_jam_thresh_dbm=-40.0).to_params()
+    x, y = dev(pos[None, :, 0], torch.float64), dev(pos[None, :, 1], torch.float64)
+    band = dev([3], torch.int32)
+    adj = torch.zeros(1, n, 1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.marl_adjacency_bits(C.byref(P), 1, x.data_ptr(), y.data_ptr(), band.data_ptr(),
+                                       adj.data_ptr(), stream()))
+    assert np.array_equal(bits_np(adj[0]), z["knife_adj"])
+    ep = z["knife_jam_epos"]
+    n = len(ep)
+    P = EnvConfig(N=n, M=1, P_jammer_dbm=20.0, P_jam_thresh_dbm=-40.0).to_params()
+    x, y = dev(ep[None, :, 0], torch.float64), dev(ep[None, :, 1], torch.float64)
+    jam = torch.zeros(1, n, 1, dtype=torch.int32, device="cuda")
+    jx, jy, jb = dev([[0.0]], torch.float64), dev([[0.0]], torch.float64), dev([[3]], torch.int32)
+    _lib.check(lib.marl_jam_mask_bits(C.byref(P), 1, x.data_ptr(), y.data_ptr(), band.data_ptr(), jx.data_ptr(),
+                                      jy.data_ptr(), jb.data_ptr(), jam.data_ptr(), stream()))
+    assert np.array_equal(bits_np(jam[0]), z["knife_jam"])
+    # reference example: jammer on the midpoint, right / wrong band, far away (tests/test_jamming.py:174-231)
+    ep = z["jam_epos"]
+    P = EnvConfig(N=3, M=1, P_jammer_dbm=20.0, P_jam_thresh_dbm=-40.0).to_params()
+    x, y = dev(ep[None, :, 0], torch.float64), dev(ep[None, :, 1], torch.float64)
+    band = dev([2], torch.int32)
+    for name, jp, b in (("on_mid", (50.0, 50.0), 2), ("wrong_band", (50.0, 50.0), 1), ("far", (50.0, 2050.0), 2)):
+        jam = torch.zeros(1, 3, 1, dtype=torch.int32, device="cuda")
+        jx, jy, jb = dev([[jp[0]]], torch.float64), dev([[jp[1]]], torch.float64), dev([[b]], torch.int32)
+        _lib.check(lib.marl_jam_mask_bits(C.byref(P), 1, x.data_ptr(), y.data_ptr(), band.data_ptr(),
+                                          jx.data_ptr(), jy.data_ptr(), jb.data_ptr(), jam.data_ptr(), stream()))
+        assert np.array_equal(bits_np(jam[0]), z[f"jam_{name}"]), name
+
+
+def test_gae_matches_reference_buffer():
+    lib = _lib.load()
+    z = gu.load("edges.npz")
+    T, E = 64, 5
+    rew = dev(np.repeat(z["gae_rew"][:, None], E, 1), torch.float32)
+    val = dev(np.repeat(z["gae_val"][:, None], E, 1), torch.float32)
+    don = dev(np.repeat(z["gae_done"][:, None], E, 1), torch.float32)
+    lv = dev(np.full(E, float(z["gae_last_value"])), torch.float32)
+    ld = dev(np.zeros(E), torch.float32)
+    adv = torch.zeros(T, E, device="cuda")
+    ret = torch.zeros(T, E, device="cuda")
+    _lib.check(lib.marl_gae(T, E, rew.data_ptr(), val.data_ptr(), don.data_ptr(), lv.data_ptr(), ld.data_ptr(),
+                            0.99, 0.95, adv.data_ptr(), ret.data_ptr(), stream()))
+    for e in range(E):
+        assert np.array_equal(ret[:, e].cpu().numpy(), z["gae_ret"])
+        a = adv[:, e].cpu().numpy()
+        np.testing.assert_allclose((a - a.mean()) / (a.std() + 1e-8), z["gae_adv_norm"], rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------- whole trajectories of the reference env
+@pytest.mark.parametrize("name", gu.TRAJ_NAMES)
+def test_trajectory_matches_reference(name):
+    z = gu.load(f"traj_{name}.npz")
+    p = gu.traj_params(z)
+    if p.N > MAXN:
+        pytest.skip("N > 64 runs on the workgroup-per-env kernels")
+    resets = gu.traj_resets(z)
+    E = 3      # the same trajectory in every env of a small batch
+    env = BatchedJammerEnv(E, cfg_from(p), auto_reset=False, track_avg_power=True, debug_bits=True)
+    rep = lambda a: np.repeat(np.asarray(a)[None], E, 0)
+
+    def do_reset(r):
+        init = r["jpos"] if p.random_jammer_start else r["offsets"]
+        obs, info = env.reset(enemy_pos=rep(r["epos"]), enemy_vel=rep(r["evel"]),
+                              enemy_band=rep(np.int32(r["band"])), jam_init=rep(init), jam_band=rep(r["jb"]))
+        torch.cuda.synchronize()
+        v = env.views
+        for e in range(E):
+            assert lam_ok(float(v["lambda2_initial"][e]), float(r["lam0"]))
+            assert np.array_equal(v["jam_x"][e].cpu().numpy(), r["jpos"][:, 0])
+            assert np.array_equal(v["jam_y"][e].cpu().numpy(), r["jpos"][:, 1])
+            assert np.array_equal(v["labels"][e].cpu().numpy(), r["labels"])
+            assert np.array_equal(v["assign"][e].cpu().numpy(), r["assign"])
+            nc = int(r["ncent"])
+            assert int(v["ncent"][e]) == nc and int(v["n_clusters"][e]) == int(r["n_clusters"])
+            assert np.array_equal(v["cent_x"][e, :nc].cpu().numpy(), r["cent_xy"][:nc, 0])
+            np.testing.assert_allclose(obs[e].cpu().numpy(), r["obs"], rtol=1e-5, atol=1e-6)
+
+    do_reset(resets[0])
+    T = len(z["reward"])
+    omega = np.array(p.omega) * np.array([1, 1, 1, -1, -1])
+    for t in range(T):
+        obs, rew, term, trunc, info = env.step(dev(rep(z["action"][t]), torch.float32),
+                                               dev(rep(z["noise"][t]), torch.float64))
+        torch.cuda.synchronize()
+        v = env.views
+        for e in (0, E - 1):
+            assert int(v["step_count"][e]) == int(z["step"][t])
+            assert np.array_equal(v["enemy_x"][e].cpu().numpy(), z["epos"][t][:, 0]), t
+            assert np.array_equal(v["enemy_y"][e].cpu().numpy(), z["epos"][t][:, 1]), t
+            assert np.array_equal(v["enemy_vx"][e].cpu().numpy(), z["evel"][t][:, 0]), t
+            assert np.array_equal(v["jam_x"][e].cpu().numpy(), z["jpos"][t][:, 0]), t
+            assert np.array_equal(v["jam_band"][e].cpu().numpy(), z["jb"][t])
+            assert np.array_equal(bits_np(env.adj_bits[e]), z["adj"][t]), t
+            assert np.array_equal(bits_np(env.jam_bits[e]), z["jam"][t]), t
+            assert np.array_equal(v["labels"][e].cpu().numpy().astype(np.int16), z["labels"][t]), t
+            nc = int(z["ncent"][t])
+            assert int(v["ncent"][e]) == nc and int(v["n_clusters"][e]) == int(z["n_clusters"][t])
+            assert np.array_equal(v["cent_x"][e, :nc].cpu().numpy(), z["cent_xy"][t][:nc, 0]), t
+            assert np.array_equal(v["cent_size"][e, :nc].cpu().numpy(), z["cent_size"][t][:nc])
+            assert np.array_equal(v["assign"][e].cpu().numpy(), z["assign"][t]), t
+            assert lam_ok(float(info["lambda2_current"][e]), float(z["lam"][t])), t
+            assert abs(float(rew[e]) - float(z["reward"][t])) <= 1e-5 * max(1.0, abs(float(z["reward"][t]))), t
+            np.testing.assert_allclose(info["reward_terms"][e].cpu().numpy().astype(np.float64) * omega,
+                                       z["comps"][t], rtol=1e-5, atol=2e-6)
+            np.testing.assert_allclose(obs[e].cpu().numpy(), z["obs"][t], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(float(info["avg_jamming_power_dbm"][e]), float(z["avgp"][t]), rtol=1e-9)
+            assert bool(trunc[e]) == bool(z["trunc"][t])
+        if bool(z["trunc"][t]):
+            do_reset(resets[t + 1])
+
+
+# ---------------------------------------------------------------- batched run vs the oracle on seeded inputs
+@pytest.mark.parametrize("N,M,E,steps", [(10, 4, 48, 25), (50, 8, 24, 21), (64, 16, 6, 11), (3, 1, 8, 12)])
+def test_batched_steps_match_oracle(N, M, E, steps):
+    rng = np.random.RandomState(100 + N)
+    p = orc.EnvParams.fast_preset(N=N, M=M)
+    p.max_steps = 15
+    env = BatchedJammerEnv(E, cfg_from(p), auto_reset=False, debug_bits=True)
+    A = p.arena_size
+
+    def draw_reset(mask):
+        epos = rng.uniform(0.1 * A, 0.9 * A, size=(E, N, 2))
+        ang = rng.uniform(0, 2 * np.pi, size=(E, N))
+        evel = np.stack([2 * np.cos(ang), 2 * np.sin(ang)], axis=2)
+        eband = rng.randint(0, 4, size=E).astype(np.int32)
+        jinit = rng.uniform(0.1 * A, 0.9 * A, size=(E, M, 2))
+        jb = rng.randint(0, 4, size=(E, M)).astype(np.int32)
+        obs, _ = env.reset(mask=None if mask is None else torch.from_numpy(mask.astype(np.uint8)),
+                           enemy_pos=epos, enemy_vel=evel, enemy_band=eband, jam_init=jinit, jam_band=jb)
+        torch.cuda.synchronize()
+        for e in range(E):
+            if mask is None or mask[e]:
+                o, _ = orc.env_reset(p, states[e], epos[e], evel[e], eband[e], jinit[e], jb[e])
+                np.testing.assert_allclose(obs[e].cpu().numpy(), o, rtol=1e-5, atol=1e-6)
+
+    states = [orc.EnvState.empty(p) for _ in range(E)]
+    draw_reset(None)
+    for t in range(steps):
+        act = rng.uniform(-6, 6, size=(E, M, 3)).astype(np.float32)
+        act[:, :, 2] = rng.uniform(-1, 5, size=(E, M))
+        # half of the envs steer their jammers onto enemy link midpoints of the enemy band
+        for e in range(0, E, 2):
+            st = states[e]
+            for j in range(M):
+                i1, i2 = rng.randint(0, N, size=2)
+                tgt = (st.enemy_pos[i1] + st.enemy_pos[i2]) / 2
+                act[e, j, :2] = np.clip((tgt - st.jammer_positions[j]) / p.dt, -7, 7)
+                act[e, j, 2] = st.enemy_band + 0.5
+        noise = rng.normal(0, 0.1, size=(E, N, 2))
+        obs, rew, _, trunc, info = env.step(torch.from_numpy(act).cuda(), torch.from_numpy(noise).cuda())
+        torch.cuda.synchronize()
+        v = env.views
+        tr = trunc.cpu().numpy()
+        for e in range(E):
+            o, r, _, tru, inf = orc.env_step(p, states[e], act[e], noise[e], want_avg_power=False)
+            st = states[e]
+            assert np.array_equal(v["enemy_x"][e].cpu().numpy(), st.enemy_pos[:, 0])
+            assert np.array_equal(v["enemy_vy"][e].cpu().numpy(), st.enemy_vel[:, 1])
+            assert np.array_equal(v["jam_y"][e].cpu().numpy(), st.jammer_positions[:, 1])
+            assert np.array_equal(bits_np(env.adj_bits[e]), orc.pack_rows(inf["adjacency"] | inf["jammed"]))
+            assert np.array_equal(bits_np(env.jam_bits[e]), orc.pack_rows(inf["jammed"]))
+            assert np.array_equal(v["labels"][e].cpu().numpy(), st.clusters.labels)
+            assert np.array_equal(v["assign"][e].cpu().numpy(), st.assign)
+            assert lam_ok(float(info["lambda2_current"][e]), inf["lambda2_current"])
+            assert abs(float(rew[e]) - r) <= 1e-5 * max(1.0, abs(r))
+            np.testing.assert_allclose(obs[e].cpu().numpy(), o, rtol=1e-5, atol=1e-6)
+            assert bool(tr[e]) == tru
+        if tr.any():
+            draw_reset(tr)
+
+
+def test_generator_mode_matches_noise_fed_mode():
+    """noise=None draws the same enemy noise that marl_fill_noise writes out."""
+    cfg = EnvConfig.fast_preset(N=50, M=8)
+    a = BatchedJammerEnv(16, cfg, seed=5, auto_reset=False)
+    b = BatchedJammerEnv(16, cfg, seed=5, auto_reset=False)
+    a.reset(); b.reset()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for t in range(12):
+        act = (torch.rand(16, 8, 3, device="cuda", generator=g) - 0.5) * 10
+        noise = b.fill_noise()
+        oa, ra, _, _, ia = a.step(act)
+        ob, rb, _, _, ib = b.step(act, noise)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb)
+        assert torch.equal(a.views["enemy_x"], b.views["enemy_x"])
+    # statistics of the generator: N(0, 0.1)
+    big = BatchedJammerEnv(2048, cfg, seed=9, auto_reset=False)
+    big.reset()
+    n = big.fill_noise()
+    assert abs(float(n.mean())) < 2e-3 and abs(float(n.std()) - 0.1) < 2e-3
+
+
+def test_on_device_reset_and_auto_reset_invariants():
+    """Generator-mode reset: positions inside [0.1A, 0.9A], unit-speed headings,
+    lambda2_initial = N for the complete graph, and auto-reset restarts step counts
+    while reporting the terminal step's metrics."""
+    cfg = EnvConfig.fast_preset(N=50, M=8, max_steps=7)
+    E = 256
+    env = BatchedJammerEnv(E, cfg, seed=3, auto_reset=True)
+    obs, info = env.reset()
+    v = env.views
+    A = cfg.arena_size
+    for k in ("enemy_x", "enemy_y", "jam_x", "jam_y"):
+        assert float(v[k].min()) >= 0.1 * A and float(v[k].max()) <= 0.9 * A
+    sp = torch.sqrt(v["enemy_vx"] ** 2 + v["enemy_vy"] ** 2)
+    assert torch.allclose(sp, torch.full_like(sp, cfg.v_enemy), rtol=1e-12, atol=0)
+    assert torch.all(v["lambda2_initial"] == 50.0)
+    assert set(v["enemy_band"].unique().cpu().numpy().tolist()) == {0, 1, 2, 3}
+    assert float(obs.min()) >= 0.0 and float(obs.max()) <= 1.0
+    x0 = v["enemy_x"].clone()
+    for t in range(1, 15):
+        act = (torch.rand(E, 8, 3, device="cuda") - 0.5) * 10
+        obs, rew, term, trunc, info = env.step(act)
+        assert not bool(term.any())
+        if t % 7 == 0:
+            assert bool(trunc.all())
+            assert torch.all(info["episode_step"] == 7)
+            assert torch.all(v["step_count"] == 0)
+            assert not torch.equal(v["enemy_x"], x0)      # fresh draw per episode
+            x0 = v["enemy_x"].clone()
+        else:
+            assert not bool(trunc.any())
+            assert torch.all(v["step_count"] == t % 7)
+        assert float(rew.min()) >= -10 and float(rew.max()) <= 10
+        assert float(obs.min()) >= 0.0 and float(obs.max()) <= 1.0
+
+
+def test_batch_of_one_equals_batch_of_many():
+    cfg = EnvConfig.fast_preset(N=50, M=8)
+    big = BatchedJammerEnv(64, cfg, seed=11, auto_reset=False)
+    big.reset()
+    one = BatchedJammerEnv(1, cfg, seed=11, auto_reset=False, env_offset=37)
+    one.reset()
+    for k in ("enemy_x", "jam_x", "enemy_band"):
+        assert torch.equal(one.views[k][0], big.views[k][37])
+    for t in range(10):
+        act = (torch.rand(64, 8, 3, device="cuda") - 0.5) * 10
+        ob, rb, _, _, ib = big.step(act)
+        oo, ro, _, _, io = one.step(act[37:38].contiguous())
+        assert torch.equal(oo[0], ob[37]) and torch.equal(ro[0], rb[37])
+        assert float(io["lambda2_current"][0]) == float(ib["lambda2_current"][37])
+
+
+# ---------------------------------------------------------------- the reference-API facade
+def test_facade_reproduces_reference_trajectory_from_seed():
+    """JammerEnv(seed).reset(seed) + the recorded actions give the reference's
+    observations and rewards: same RandomState consumption as the reference."""
+    z = gu.load("traj_n10m4_random.npz")
+    p = gu.traj_params(z)
+    np.random.seed(42 + 1000)
+    env = JammerEnv(M=p.M, N=p.N, seed=42, arena_size=p.arena_size, max_steps=p.max_steps,
+                    P_jammer_dbm=p.P_jammer_dbm, P_jam_thresh_dbm=p.P_jam_thresh_dbm, eps=p.eps,
+                    random_jammer_start=True)
+    resets = gu.traj_resets(z)
+    obs, info = env.reset(seed=42)
+    np.testing.assert_allclose(obs, resets[0]["obs"], rtol=1e-5, atol=1e-6)
+    assert info["enemy_band"] == int(resets[0]["band"]) and info["step"] == 0
+    assert lam_ok(info["lambda2_initial"], float(resets[0]["lam0"]))
+    for t in range(260):
+        obs, reward, term, trunc, info = env.step(z["action"][t])
+        assert obs.dtype == np.float32 and obs.shape == (p.M, 5)
+        np.testing.assert_allclose(obs, z["obs"][t], rtol=1e-5, atol=1e-6)
+        assert abs(reward - float(z["reward"][t])) <= 1e-5 * max(1.0, abs(float(z["reward"][t])))
+        assert np.array_equal(info["enemy_positions"], z["epos"][t])
+        assert np.array_equal(info["jammer_positions"], z["jpos"][t])
+        assert term is False and trunc == bool(z["trunc"][t])
+        assert set(info) >= {"lambda2_initial", "lambda2_current", "lambda2_reduction", "lambda2_reduction_raw",
+                             "enemy_band", "n_clusters", "step", "reward_components", "jammer_positions",
+                             "enemy_positions", "avg_jamming_power_dbm"}
+        if trunc:
+            obs, info = env.reset()
+            np.testing.assert_allclose(obs, resets[t + 1]["obs"], rtol=1e-5, atol=1e-6)
+
+
+def test_facade_centroid_start_and_api_contract():
+    """random_jammer_start=False path (global-RNG offsets) and the step contract the
+    reference's tests/test_jammer_env.py:181-250,294-306 pin."""
+    z = gu.load("traj_n20m4_centroid.npz")
+    p = gu.traj_params(z)
+    np.random.seed(5 + 1000)
+    env = JammerEnv(M=p.M, N=p.N, seed=5, arena_size=p.arena_size, max_steps=p.max_steps,
+                    P_jammer_dbm=p.P_jammer_dbm, P_jam_thresh_dbm=p.P_jam_thresh_dbm, eps=p.eps,
+                    random_jammer_start=False)
+    resets = gu.traj_resets(z)
+    obs, info = env.reset(seed=5)
+    assert np.array_equal(env.jammer_positions, resets[0]["jpos"])
+    np.testing.assert_allclose(obs, resets[0]["obs"], rtol=1e-5, atol=1e-6)
+    for t in range(70):
+        obs, reward, term, trunc, info = env.step(z["action"][t])
+        np.testing.assert_allclose(obs, z["obs"][t], rtol=1e-5, atol=1e-6)
+        if trunc:
+            obs, info = env.reset()
+            assert np.array_equal(env.jammer_positions, resets[t + 1]["jpos"])
+    # pos += v*dt; bands from the action; dict actions; settable jammer_positions
+    env = JammerEnv(M=2, N=5, seed=1, max_steps=5)
+    env.reset(seed=1)
+    env.jammer_positions = np.array([[100.0, 100.0], [50.0, 50.0]])
+    obs, r, term, trunc, info = env.step({"velocity": np.array([[2.0, 0.0], [0.0, -2.0]], dtype=np.float32),
+                                          "band": np.array([1, 3])})
+    assert np.allclose(env.jammer_positions, [[101.0, 100.0], [50.0, 49.0]])
+    assert list(env.jammer_bands) == [1, 3]
+    assert obs.min() >= 0 and obs.max() <= 1
+    for _ in range(4):
+        obs, r, term, trunc, info = env.step(np.zeros((2, 3), dtype=np.float32))
+    assert trunc and not term and info["step"] == 5
