@@ -30,6 +30,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "marl_env.h"
 
 namespace {
@@ -107,8 +109,9 @@ __device__ __forceinline__ void noise_pair(uint64_t seed, uint64_t genv, uint32_
 struct WaveLds {
     double sx[WAVE], sy[WAVE];        // enemy positions
     double jx[WAVE], jy[WAVE];        // jammer positions
-    double u[WAVE], q[WAVE];          // Householder vectors
+    double2 uq[WAVE];                 // Householder vectors (u_c, q_c) interleaved for one 16-byte broadcast read
     double dd[WAVE], e2[WAVE];        // tridiagonal: diagonal, squared off-diagonal
+    unsigned long long xfer[WAVE];    // lane-to-lane hand-over of 64-bit rows
     double cx[WAVE + 2], cy[WAVE + 2];  // centroids in dict order
     double px[WAVE + 2], py[WAVE + 2];  // previous centroids
     int csz[WAVE + 2];
@@ -117,8 +120,7 @@ struct WaveLds {
     int jb[WAVE];
 };
 
-__host__ __device__ inline int mat_ld(int n) { return n | 1; }   // odd leading dimension: conflict-free column reads
-inline size_t wave_lds_bytes(int n) { return sizeof(WaveLds) + (size_t)n * mat_ld(n) * sizeof(double); }
+inline size_t wave_lds_bytes(int) { return sizeof(WaveLds); }
 
 // ------------------------------------------------------------------ pairwise bit rows
 // Row `lane` of the FSPL adjacency (communication_graph.py:41-105): bit j set iff
@@ -155,18 +157,109 @@ __device__ __forceinline__ uint64_t jam_row(const WaveLds& L, int n, int m, int 
 }
 
 // ------------------------------------------------------------------ lambda2
+// Sum over the 64 lanes without LDS traffic: rotate-and-add inside each row of 16
+// lanes with DPP moves, then the four row totals through SGPRs.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int src) {      // src wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_mov<0x128>(v);      // row_ror:8
+    v += dpp_mov<0x124>(v);      // row_ror:4
+    v += dpp_mov<0x122>(v);      // row_ror:2
+    v += dpp_mov<0x121>(v);      // row_ror:1
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+
+// Column loops of the register-resident Householder step.  Row j of the matrix lives in
+// the registers a[0..NPAD) of lane j, so every index must be a constant already when the
+// code is parsed (a loop variable, even of a fully unrollable loop, makes the compiler
+// keep the array in scratch memory): loops are expanded by template recursion, in blocks
+// of 8 columns with a wave-uniform exit after the block that holds column l.  Columns
+// l+1.. of the last block are no-ops because u and q are zero there.
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+
+template <int NPAD, int B>
+struct ColBlocks {
+    // p += A[:, 8B..8B+7] * u[8B..8B+7]; u_c comes from lane c through SGPRs
+    static __device__ __forceinline__ void matvec(const double (&a)[NPAD], double uj, int l, double& p0, double& p1) {
+        if constexpr (B * 8 < NPAD) {
+            if (B * 8 > l) return;
+            static_for<0, 4>([&](auto k) {
+                constexpr int c = B * 8 + 2 * decltype(k)::value;
+                p0 = fma(a[c], readlane_d(uj, c), p0);
+                p1 = fma(a[c + 1], readlane_d(uj, c + 1), p1);
+            });
+            asm volatile("" : "+v"(p0), "+v"(p1));
+            ColBlocks<NPAD, B + 1>::matvec(a, uj, l, p0, p1);
+        }
+    }
+    // A[:, c] -= u q_c + q u_c; (u_c, q_c) by one 16-byte broadcast LDS read per column
+    static __device__ __forceinline__ void update(double (&a)[NPAD], double uj, double qj, int l, const double2* uq) {
+        if constexpr (B * 8 < NPAD) {
+            if (B * 8 > l) return;
+            static_for<0, 8>([&](auto k) {
+                constexpr int c = B * 8 + decltype(k)::value;
+                const double2 t = uq[c];
+                a[c] = fma(-uj, t.y, fma(-qj, t.x, a[c]));
+            });
+            // pin this block's results here: without it the compiler issues every block's loads
+            // first and sinks all the arithmetic behind them, which needs 4 registers per column
+            asm volatile("" : "+v"(a[B * 8]), "+v"(a[B * 8 + 1]), "+v"(a[B * 8 + 2]), "+v"(a[B * 8 + 3]),
+                              "+v"(a[B * 8 + 4]), "+v"(a[B * 8 + 5]), "+v"(a[B * 8 + 6]), "+v"(a[B * 8 + 7])
+                         :: "memory");
+            ColBlocks<NPAD, B + 1>::update(a, uj, qj, l, uq);
+        }
+    }
+};
+
+// a[i] for a wave-uniform runtime i in [LO, HI): binary search by uniform branches
+template <int NPAD, int LO, int HI>
+__device__ __forceinline__ double column_of(const double (&a)[NPAD], int i) {
+    if constexpr (HI - LO == 1) {
+        double v = a[LO];
+        asm volatile("" : "+v"(v));      // opaque leaf: stops the compiler from rebuilding a dynamic a[i] (scratch array)
+        return v;
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (i < MID) return column_of<NPAD, LO, MID>(a, i);
+        return column_of<NPAD, MID, HI>(a, i);
+    }
+}
+
 // Second-smallest eigenvalue of L = D - A for the graph whose adjacency rows are
 // `row` (communication_graph.py:184-286; the reference calls LAPACK dsyevr through
-// scipy.linalg.eigh(subset_by_index=[0,1])).  Here: exact shortcuts for the
-// complete graph (lambda2 = n) and for disconnected graphs (lambda2 = 0), else
-// Householder tridiagonalisation of L in LDS (lane j owns row j) followed by a
-// 64-way multisection on the Sturm count of the tridiagonal matrix.
-__device__ double lambda2_wave(uint64_t row, int n, int lane, WaveLds& L, double* A, int rounds) {
+// scipy.linalg.eigh(subset_by_index=[0,1])).
+//
+//   * complete graph -> n, disconnected graph -> 0 (exact, one ballot per BFS level);
+//   * otherwise lambda2(G) = n - mu_max(complement of G): L(G) + L(G') = n I - J, so on
+//     the space orthogonal to the all-ones vector the spectra mirror each other.  Only
+//     the n' vertices that miss at least one neighbour carry edges of the complement;
+//     they are compacted to lanes 0..n'-1 and the n' x n' Laplacian of the complement is
+//     tridiagonalised by Householder reflections with row j held in the registers of
+//     lane j (no matrix in LDS), then mu_max is bracketed by 64-way multisection on
+//     the sign changes of the Sturm sequence of the tridiagonal matrix.
+template <int NPAD>
+__device__ __forceinline__ double lambda2_wave(uint64_t row, int n, int lane, WaveLds& L, int rounds) {
     if (n <= 1) return 0.0;
     const int deg = __popcll(row);
     const uint64_t active = (n >= 64) ? ~0ull : ((1ull << n) - 1);
-    if (ballot64(lane < n && deg == n - 1) == active) return (double)n;
-    {   // connectivity: breadth-first search from vertex 0, one ballot per level
+    const uint64_t touched = ballot64(lane < n && deg < n - 1);
+    if (touched == 0) return (double)n;
+    {   // connectivity: breadth-first search from vertex 0
         uint64_t comp = 1ull, frontier = 1ull;
         while (frontier) {
             const uint64_t hit = ballot64((row & frontier) != 0);
@@ -176,83 +269,99 @@ __device__ double lambda2_wave(uint64_t row, int n, int lane, WaveLds& L, double
         }
         if (comp != active) return 0.0;
     }
-    const int ld = mat_ld(n);
-    if (lane < n) {
-        double* Ar = A + lane * ld;
-        for (int k = 0; k < n; ++k) Ar[k] = (k == lane) ? (double)deg : -(double)((row >> k) & 1ull);
+    // complement rows restricted to the touched vertices, compacted
+    const int np = __popcll(touched);
+    const uint64_t crow_full = ~row & active & ~(1ull << lane) & touched;
+    uint64_t crow = 0;
+    {
+        uint64_t t = touched;
+        int k = 0;
+        while (t) {
+            const int v = __ffsll((unsigned long long)t) - 1;
+            crow |= ((crow_full >> v) & 1ull) << k;
+            t &= t - 1;
+            ++k;
+        }
     }
     WSYNC();
-    for (int i = n - 1; i >= 2; --i) {
+    if ((touched >> lane) & 1ull) L.xfer[__popcll(touched & ((1ull << lane) - 1))] = crow;
+    WSYNC();
+    crow = (lane < np) ? L.xfer[lane] : 0ull;
+    const int cdeg = __popcll(crow);
+    int dmax = cdeg;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
+
+    double a[NPAD];
+    static_for<0, NPAD>([&](auto k) {
+        constexpr int c = decltype(k)::value;
+        a[c] = (c == lane) ? (double)cdeg : -(double)((crow >> c) & 1ull);
+    });
+
+    for (int i = np - 1; i >= 2; --i) {
         const int l = i - 1;
-        double uj = (lane <= l) ? A[i * ld + lane] : 0.0;
-        double h = wave_sum(uj * uj);
-        if (lane == 0) { L.dd[i] = A[i * ld + i]; L.e2[i] = h; }
-        if (h == 0.0) continue;                       // row already reduced
-        const double f = bcast(uj, l);
+        const double col = column_of<NPAD, 0, NPAD>(a, i);     // A[lane][i] == A[i][lane]
+        const double aii = readlane_d(col, i);
+        double uj = (lane <= l) ? col : 0.0;
+        double h = wave_sum_dpp(uj * uj);
+        if (lane == 0) { L.dd[i] = aii; L.e2[i] = h; }
+        if (h == 0.0) continue;                         // row already reduced
+        const double f = readlane_d(uj, l);
         const double g = (f >= 0.0) ? -sqrt(h) : sqrt(h);
         h -= f * g;
         if (lane == l) uj = f - g;
-        L.u[lane] = uj;
+        // p = A u / h : u_c reaches every lane through SGPRs
+        double p0 = 0.0, p1 = 0.0;
+        ColBlocks<NPAD, 0>::matvec(a, uj, l, p0, p1);
+        const double hinv = 1.0 / h;
+        const double p = (lane <= l) ? (p0 + p1) * hinv : 0.0;
+        const double K = wave_sum_dpp(uj * p) * (0.5 * hinv);
+        const double qj = (lane <= l) ? fma(-K, uj, p) : 0.0;
+        L.uq[lane] = make_double2(uj, qj);
         WSYNC();
-        double p = 0.0;
-        if (lane <= l) {
-            const double* Ar = A + lane * ld;
-            double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-            int k = 0;
-            for (; k + 3 <= l; k += 4) {
-                p0 = fma(Ar[k], L.u[k], p0);
-                p1 = fma(Ar[k + 1], L.u[k + 1], p1);
-                p2 = fma(Ar[k + 2], L.u[k + 2], p2);
-                p3 = fma(Ar[k + 3], L.u[k + 3], p3);
-            }
-            for (; k <= l; ++k) p0 = fma(Ar[k], L.u[k], p0);
-            p = ((p0 + p1) + (p2 + p3)) / h;
-        }
-        const double K = wave_sum(uj * p) / (h + h);
-        const double qj = p - K * uj;
-        L.q[lane] = qj;
-        WSYNC();
-        if (lane <= l) {
-            double* Ar = A + lane * ld;
-            for (int k = 0; k <= l; ++k) Ar[k] = fma(-uj, L.q[k], fma(-qj, L.u[k], Ar[k]));
-        }
+        // A -= u q^T + q u^T : (u_c, q_c) by one broadcast LDS read per column
+        ColBlocks<NPAD, 0>::update(a, uj, qj, l, L.uq);
         WSYNC();
     }
-    if (lane == 0) {
-        L.dd[1] = A[ld + 1];
-        L.e2[1] = A[ld] * A[ld];
-        L.dd[0] = A[0];
-        L.e2[0] = 0.0;
+    {
+        const double a11 = readlane_d(a[1], 1), a10 = readlane_d(a[0], 1), a00 = readlane_d(a[0], 0);
+        if (lane == 0) { L.dd[1] = a11; L.e2[1] = a10 * a10; L.dd[0] = a00; L.e2[0] = 0.0; }
     }
     WSYNC();
-    // multisection: lane t counts eigenvalues below x_t; the second-smallest lies
-    // between the last x with count <= 1 and the first with count >= 2.
-    double lo = -1e-7, hi = (double)n * (1.0 + 1e-9) + 1e-7;
-    const double pivmin = 1e-290;
+    // mu_max in [dmax + 1, min(n', 2 dmax)] (Laplacian bounds for a graph with an edge).
+    // Lane t evaluates the Sturm sequence p_0 = 1, p_k = (d_k - x) p_{k-1} - e_k^2 p_{k-2}
+    // at x_t; its sign changes count the eigenvalues below x_t.
+    double lo = (double)(dmax + 1) * (1.0 - 1e-13) - 1e-13;
+    double hi = (double)min(np, 2 * dmax) * (1.0 + 1e-13) + 1e-13;
     for (int r = 0; r < rounds; ++r) {
+        if (hi - lo <= 2e-12 * hi) break;
         const double w = (hi - lo) * (1.0 / 65.0);
         const double x = lo + w * (double)(lane + 1);
-        double qv = L.dd[0] - x;
-        int cnt = qv < 0.0;
-        for (int i = 1; i < n; ++i) {
-            if (fabs(qv) < pivmin) qv = -pivmin;
-            double rc = __builtin_amdgcn_rcp(qv);
-            rc = fma(fma(-qv, rc, 1.0), rc, rc);
-            qv = (L.dd[i] - x) - L.e2[i] * rc;
-            cnt += qv < 0.0;
+        double pm = 1.0, pc = L.dd[0] - x;
+        int cnt = (unsigned)__double2hiint(pc) >> 31;
+        for (int i = 1; i < np; ++i) {
+            const double pn = fma(L.dd[i] - x, pc, -(L.e2[i] * pm));
+            cnt += ((unsigned)(__double2hiint(pn) ^ __double2hiint(pc))) >> 31;
+            pm = pc;
+            pc = pn;
+            if ((i & 7) == 7) {                         // keep the recurrence inside the exponent range
+                const int ex = __builtin_amdgcn_frexp_exp(fabs(pc) > fabs(pm) ? pc : pm);
+                pc = ldexp(pc, -ex);
+                pm = ldexp(pm, -ex);
+            }
         }
-        const uint64_t ge2 = ballot64(cnt >= 2);
-        if (ge2 == 0) {
-            lo = bcast(x, WAVE - 1);
+        const uint64_t all = ballot64(cnt >= np);
+        if (all == 0) {
+            lo = readlane_d(x, WAVE - 1);
         } else {
-            const int t = __ffsll((unsigned long long)ge2) - 1;
-            const double xh = bcast(x, t);
-            const double xl = bcast(x, t > 0 ? t - 1 : 0);
+            const int t = __ffsll((unsigned long long)all) - 1;
+            const double xh = readlane_d(x, t);
+            const double xl = readlane_d(x, t > 0 ? t - 1 : 0);
             hi = xh;
             if (t > 0) lo = xl;
         }
     }
-    return 0.5 * (lo + hi);
+    return (double)n - 0.5 * (lo + hi);
 }
 
 // ------------------------------------------------------------------ DBSCAN + centroids
@@ -260,7 +369,7 @@ __device__ double lambda2_wave(uint64_t row, int n, int lane, WaveLds& L, double
 // (dbscan_clustering.py:113), then centroids / sizes in dict order
 // (dbscan_clustering.py:116-128, 130-144, 230-260) into L.cx/L.cy/L.csz.
 // Returns the lane's label; n_clusters and ncent by reference (wave-uniform).
-__device__ int dbscan_wave(const MarlEnvParams& P, int n, int lane, WaveLds& L, int& n_clusters, int& ncent) {
+__device__ __forceinline__ int dbscan_wave(const MarlEnvParams& P, int n, int lane, WaveLds& L, int& n_clusters, int& ncent) {
     const double eps2 = P.eps * P.eps;
     uint64_t nb = 0;
     {
@@ -318,7 +427,7 @@ __device__ int dbscan_wave(const MarlEnvParams& P, int n, int lane, WaveLds& L, 
 
 // should_reassign_jammers(drift_threshold) (dbscan_clustering.py:163-204) on the
 // current (L.cx..) and previous (L.px..) centroid tables.
-__device__ bool should_reassign_wave(const MarlEnvParams& P, int lane, const WaveLds& L, int num, int ncent,
+__device__ __forceinline__ bool should_reassign_wave(const MarlEnvParams& P, int lane, const WaveLds& L, int num, int ncent,
                                      int pnum, int pncent) {
     bool mine = false;
     for (int s = lane; s < ncent; s += WAVE) {
@@ -333,7 +442,7 @@ __device__ bool should_reassign_wave(const MarlEnvParams& P, int lane, const Wav
 }
 
 // assign_jammers_to_clusters(strategy="proportional") (dbscan_clustering.py:263-362) into L.asg.
-__device__ void assign_proportional_wave(int m, int lane, WaveLds& L, int num, int ncent) {
+__device__ __forceinline__ void assign_proportional_wave(int m, int lane, WaveLds& L, int num, int ncent) {
     if (lane == 0 && m > 0 && ncent > 0) {
         const int first = 0;
         const int nvalid = (num > 0) ? num : ncent;        // all-noise: the -1 entry is the one cluster
@@ -360,14 +469,14 @@ __device__ void assign_proportional_wave(int m, int lane, WaveLds& L, int num, i
 }
 
 // ------------------------------------------------------------------ reward + observation
-struct RewardOut { double total; float r[5]; };
+struct RewardOut { double total; float r0, r1, r2, r3, r4; float o0, o1, o2, o3, o4; };
 
 // RewardCalculator.compute (reward.py:106-306) and ObservationBuilder.build_vectorized
 // (observation.py:264-332).  Lane j < m owns jammer j.  obs_row receives the five
 // features of the lane's jammer.
-__device__ RewardOut reward_obs_wave(const MarlEnvParams& P, int n, int m, int lane, const WaveLds& L,
+__device__ __forceinline__ RewardOut reward_obs_wave(const MarlEnvParams& P, int n, int m, int lane, const WaveLds& L,
                                      int eband, int num, int ncent, double lam, double lam0,
-                                     float raw_vx, float raw_vy, float obs_row[5]) {
+                                     float raw_vx, float raw_vy) {
     RewardOut out;
     const bool act = lane < m;
     const double A = P.arena_size;
@@ -420,19 +529,19 @@ __device__ RewardOut reward_obs_wave(const MarlEnvParams& P, int n, int m, int l
     const float r4 = wave_sum(en) / (float)m;
     const double raw = P.omega[0] * r1 + P.omega[1] * r2 + P.omega[2] * r3 - P.omega[3] * (double)r4 - P.omega[4] * r5;
     out.total = fmin(fmax(raw, -10.0), 10.0);
-    out.r[0] = (float)r1; out.r[1] = (float)r2; out.r[2] = (float)r3; out.r[3] = r4; out.r[4] = (float)r5;
+    out.r0 = (float)r1; out.r1 = (float)r2; out.r2 = (float)r3; out.r3 = r4; out.r4 = (float)r5;
     // observation
-    obs_row[0] = (float)fmin(fmax(best / A, 0.0), 1.0);
-    obs_row[1] = (n > 0 && ncent > 0) ? (float)((double)L.csz[bslot] / (double)n) : 0.0f;
-    obs_row[2] = (m > 1) ? (float)fmin(fmax(dsum / (double)(m - 1) / A, 0.0), 1.0) : 0.5f;
-    obs_row[3] = (float)r5;
-    obs_row[4] = match ? 1.0f : 0.0f;
+    out.o0 = (float)fmin(fmax(best / A, 0.0), 1.0);
+    out.o1 = (n > 0 && ncent > 0) ? (float)((double)L.csz[bslot] / (double)n) : 0.0f;
+    out.o2 = (m > 1) ? (float)fmin(fmax(dsum / (double)(m - 1) / A, 0.0), 1.0) : 0.5f;
+    out.o3 = (float)r5;
+    out.o4 = match ? 1.0f : 0.0f;
     return out;
 }
 
 // _compute_avg_jamming_power (jammer_env.py:510-560): mean over links i<j of the
 // strongest matching jammer's power at the link midpoint, in dBm; -80 when none.
-__device__ double avg_power_wave(const MarlEnvParams& P, int n, int m, int lane, const WaveLds& L, int eband) {
+__device__ __forceinline__ double avg_power_wave(const MarlEnvParams& P, int n, int m, int lane, const WaveLds& L, int eband) {
     int nm = 0;
     for (int k = 0; k < m; ++k) nm += (L.jb[k] == eband);
     if (nm == 0) return -80.0;
@@ -469,17 +578,13 @@ __device__ __forceinline__ void store_bits(uint32_t* dst, int e, int n, int lane
     if (W > 1) p[1] = (uint32_t)(row >> 32);
 }
 
-__device__ __forceinline__ WaveLds& carve(unsigned char* smem, double*& A) {
-    WaveLds& L = *reinterpret_cast<WaveLds*>(smem);
-    A = reinterpret_cast<double*>(smem + sizeof(WaveLds));
-    return L;
-}
+__device__ __forceinline__ WaveLds& carve(unsigned char* smem) { return *reinterpret_cast<WaveLds*>(smem); }
 
 // ------------------------------------------------------------------ step kernel (N <= 64)
+template <int NPAD>
 __global__ __launch_bounds__(WAVE) void env_step_wave_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double* A;
-    WaveLds& L = carve(smem, A);
+    WaveLds& L = carve(smem);
     const int e = blockIdx.x, lane = threadIdx.x;
     const int n = P.N, m = P.M, KS = n + 1;
     const int step = S.step_count[e] + 1;
@@ -570,17 +675,18 @@ __global__ __launch_bounds__(WAVE) void env_step_wave_kernel(MarlEnvParams P, Ma
     const uint64_t jam = jam_row(L, n, m, lane, eband, P.jam_d2_max[eband]);
     store_bits(io.adj_bits, e, n, lane, adj);
     store_bits(io.jam_bits, e, n, lane, jam);
-    const double lam = lambda2_wave(adj & ~jam, n, lane, L, A, P.lambda2_rounds);
+    const double lam = lambda2_wave<NPAD>(adj & ~jam, n, lane, L, P.lambda2_rounds);
     const double lam0 = S.lambda2_initial[e];
     // -- reward, observation (jammer_env.py:414-438)
-    float obs_row[5];
-    const RewardOut rw = reward_obs_wave(P, n, m, lane, L, eband, num, ncent, lam, lam0, raw_vx, raw_vy, obs_row);
+    const RewardOut rw = reward_obs_wave(P, n, m, lane, L, eband, num, ncent, lam, lam0, raw_vx, raw_vy);
     if (lane < m) {
         float* o = io.obs + ((size_t)e * m + lane) * MARL_OBS_DIM;
-#pragma unroll
-        for (int c = 0; c < MARL_OBS_DIM; ++c) o[c] = obs_row[c];
+        o[0] = rw.o0; o[1] = rw.o1; o[2] = rw.o2; o[3] = rw.o3; o[4] = rw.o4;
     }
-    if (io.reward_terms && lane < 5) io.reward_terms[(size_t)e * 5 + lane] = rw.r[lane];
+    if (io.reward_terms && lane == 0) {
+        float* r = io.reward_terms + (size_t)e * 5;
+        r[0] = rw.r0; r[1] = rw.r1; r[2] = rw.r2; r[3] = rw.r3; r[4] = rw.r4;
+    }
     double avgp = 0.0;
     if (io.avg_power_dbm) avgp = avg_power_wave(P, n, m, lane, L, eband);
     if (lane == 0) {
@@ -593,10 +699,10 @@ __global__ __launch_bounds__(WAVE) void env_step_wave_kernel(MarlEnvParams P, Ma
 }
 
 // ------------------------------------------------------------------ reset kernel (N <= 64)
+template <int NPAD>
 __global__ __launch_bounds__(WAVE) void env_reset_wave_kernel(MarlEnvParams P, MarlEnvState S, MarlResetIO io) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double* A;
-    WaveLds& L = carve(smem, A);
+    WaveLds& L = carve(smem);
     const int e = blockIdx.x, lane = threadIdx.x;
     if (io.mask && io.mask[e] == 0) return;
     const int n = P.N, m = P.M, KS = n + 1;
@@ -663,7 +769,7 @@ __global__ __launch_bounds__(WAVE) void env_reset_wave_kernel(MarlEnvParams P, M
         WSYNC();
         // lambda2 of the un-jammed graph (jammer_env.py:301)
         const uint64_t adj = adjacency_row(L, n, lane, P.comm_d2_max[eband]);
-        lam0 = lambda2_wave(adj, n, lane, L, A, P.lambda2_rounds);
+        lam0 = lambda2_wave<NPAD>(adj, n, lane, L, P.lambda2_rounds);
         if (lam0 >= P.min_lambda2_initial) break;
     }
     // jammers (jammer_env.py:321-339)
@@ -713,12 +819,10 @@ __global__ __launch_bounds__(WAVE) void env_reset_wave_kernel(MarlEnvParams P, M
         L.jx[lane] = x; L.jy[lane] = y; L.jb[lane] = band;
     }
     WSYNC();
-    float obs_row[5];
-    (void)reward_obs_wave(P, n, m, lane, L, eband, num, ncent, lam0, lam0, 0.0f, 0.0f, obs_row);
+    const RewardOut rw = reward_obs_wave(P, n, m, lane, L, eband, num, ncent, lam0, lam0, 0.0f, 0.0f);
     if (lane < m && io.obs) {
         float* o = io.obs + ((size_t)e * m + lane) * MARL_OBS_DIM;
-#pragma unroll
-        for (int c = 0; c < MARL_OBS_DIM; ++c) o[c] = obs_row[c];
+        o[0] = rw.o0; o[1] = rw.o1; o[2] = rw.o2; o[3] = rw.o3; o[4] = rw.o4;
     }
     if (lane == 0) {
         S.step_count[e] = 0;
@@ -731,8 +835,7 @@ __global__ __launch_bounds__(WAVE) void env_reset_wave_kernel(MarlEnvParams P, M
 __global__ __launch_bounds__(WAVE) void adjacency_bits_kernel(MarlEnvParams P, const double* x, const double* y,
                                                               const int32_t* band, uint32_t* bits) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double* A;
-    WaveLds& L = carve(smem, A);
+    WaveLds& L = carve(smem);
     const int e = blockIdx.x, lane = threadIdx.x, n = P.N;
     if (lane < n) { L.sx[lane] = x[(size_t)e * n + lane]; L.sy[lane] = y[(size_t)e * n + lane]; }
     WSYNC();
@@ -744,8 +847,7 @@ __global__ __launch_bounds__(WAVE) void jam_bits_kernel(MarlEnvParams P, const d
                                                         const int32_t* band, const double* jx, const double* jy,
                                                         const int32_t* jb, uint32_t* bits) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double* A;
-    WaveLds& L = carve(smem, A);
+    WaveLds& L = carve(smem);
     const int e = blockIdx.x, lane = threadIdx.x, n = P.N, m = P.M;
     if (lane < n) { L.sx[lane] = x[(size_t)e * n + lane]; L.sy[lane] = y[(size_t)e * n + lane]; }
     if (lane < m) {
@@ -757,10 +859,10 @@ __global__ __launch_bounds__(WAVE) void jam_bits_kernel(MarlEnvParams P, const d
     store_bits(bits, e, n, lane, jam_row(L, n, m, lane, b, P.jam_d2_max[b]));
 }
 
+template <int NPAD>
 __global__ __launch_bounds__(WAVE) void lambda2_bits_kernel(int n, const uint32_t* bits, double* lambda2, int rounds) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double* A;
-    WaveLds& L = carve(smem, A);
+    WaveLds& L = carve(smem);
     const int e = blockIdx.x, lane = threadIdx.x;
     const int W = (n + 31) / 32;
     uint64_t row = 0;
@@ -771,7 +873,7 @@ __global__ __launch_bounds__(WAVE) void lambda2_bits_kernel(int n, const uint32_
         row &= ~(1ull << lane);
         if (n < 64) row &= (1ull << n) - 1;
     }
-    const double lam = lambda2_wave(row, n, lane, L, A, rounds);
+    const double lam = lambda2_wave<NPAD>(row, n, lane, L, rounds);
     if (lane == 0) lambda2[e] = lam;
 }
 
@@ -779,8 +881,7 @@ __global__ __launch_bounds__(WAVE) void dbscan_kernel(MarlEnvParams P, const dou
                                                       int32_t* labels, double* cx, double* cy, int32_t* csz,
                                                       int32_t* n_clusters, int32_t* ncent_out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double* A;
-    WaveLds& L = carve(smem, A);
+    WaveLds& L = carve(smem);
     const int e = blockIdx.x, lane = threadIdx.x, n = P.N, KS = n + 1;
     if (lane < n) { L.sx[lane] = x[(size_t)e * n + lane]; L.sy[lane] = y[(size_t)e * n + lane]; }
     WSYNC();
@@ -875,6 +976,21 @@ int check_sizes(const MarlEnvParams* p) {
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// The wave kernels are instantiated per register-matrix width NPAD = N rounded up to 8.
+#define MARL_LAUNCH_NPAD(NP, kern, grid, lds, stream, ...) \
+    hipLaunchKernelGGL((kern<NP>), grid, dim3(WAVE), lds, (hipStream_t)(stream), __VA_ARGS__)
+#define MARL_DISPATCH_NPAD(N, kern, grid, lds, stream, ...)                                   \
+    switch (((N) + 7) / 8) {                                                                   \
+        case 1: MARL_LAUNCH_NPAD(8, kern, grid, lds, stream, __VA_ARGS__); break;              \
+        case 2: MARL_LAUNCH_NPAD(16, kern, grid, lds, stream, __VA_ARGS__); break;             \
+        case 3: MARL_LAUNCH_NPAD(24, kern, grid, lds, stream, __VA_ARGS__); break;             \
+        case 4: MARL_LAUNCH_NPAD(32, kern, grid, lds, stream, __VA_ARGS__); break;             \
+        case 5: MARL_LAUNCH_NPAD(40, kern, grid, lds, stream, __VA_ARGS__); break;             \
+        case 6: MARL_LAUNCH_NPAD(48, kern, grid, lds, stream, __VA_ARGS__); break;             \
+        case 7: MARL_LAUNCH_NPAD(56, kern, grid, lds, stream, __VA_ARGS__); break;             \
+        default: MARL_LAUNCH_NPAD(64, kern, grid, lds, stream, __VA_ARGS__); break;            \
+    }
+
 }  // namespace
 
 // ====================================================================== C ABI
@@ -908,7 +1024,7 @@ int marl_params_init(MarlEnvParams* p) {
     p->v_max_f32 = (float)p->v_max;
     p->v_max_sq_f32 = (float)(p->v_max * p->v_max);
     p->pad_f32 = 0.0f;
-    if (p->lambda2_rounds <= 0) p->lambda2_rounds = 7;
+    if (p->lambda2_rounds <= 0) p->lambda2_rounds = 8;
     return MARL_OK;
 }
 
@@ -966,8 +1082,7 @@ int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepI
         io->truncated == nullptr || s->enemy_x == nullptr)
         return MARL_EINVAL;
     if (p->N > WAVE) return MARL_EUNSUPPORTED;
-    hipLaunchKernelGGL(env_step_wave_kernel, dim3(s->E), dim3(WAVE), wave_lds_bytes(p->N), (hipStream_t)stream,
-                       *p, *s, *io);
+    MARL_DISPATCH_NPAD(p->N, env_step_wave_kernel, dim3(s->E), wave_lds_bytes(p->N), stream, *p, *s, *io);
     return hip_check(hipGetLastError());
 }
 
@@ -978,8 +1093,7 @@ int marl_env_reset(const MarlEnvParams* p, const MarlEnvState* s, const MarlRese
     if (s->E < 1 || s->enemy_x == nullptr) return MARL_EINVAL;
     if ((io->enemy_pos == nullptr) != (io->enemy_vel == nullptr)) return MARL_EINVAL;
     if (p->N > WAVE) return MARL_EUNSUPPORTED;
-    hipLaunchKernelGGL(env_reset_wave_kernel, dim3(s->E), dim3(WAVE), wave_lds_bytes(p->N), (hipStream_t)stream,
-                       *p, *s, *io);
+    MARL_DISPATCH_NPAD(p->N, env_reset_wave_kernel, dim3(s->E), wave_lds_bytes(p->N), stream, *p, *s, *io);
     return hip_check(hipGetLastError());
 }
 
@@ -989,7 +1103,7 @@ int marl_adjacency_bits(const MarlEnvParams* p, int32_t E, const double* x, cons
     if (rc != MARL_OK) return rc;
     if (E < 1 || !x || !y || !band || !bits) return MARL_EINVAL;
     if (p->N > WAVE) return MARL_EUNSUPPORTED;
-    hipLaunchKernelGGL(adjacency_bits_kernel, dim3(E), dim3(WAVE), sizeof(WaveLds), (hipStream_t)stream, *p, x, y,
+    hipLaunchKernelGGL(adjacency_bits_kernel, dim3(E), dim3(WAVE), wave_lds_bytes(p->N), (hipStream_t)stream, *p, x, y,
                        band, bits);
     return hip_check(hipGetLastError());
 }
@@ -1001,7 +1115,7 @@ int marl_jam_mask_bits(const MarlEnvParams* p, int32_t E, const double* x, const
     if (rc != MARL_OK) return rc;
     if (E < 1 || !x || !y || !band || !jam_x || !jam_y || !jam_band || !bits) return MARL_EINVAL;
     if (p->N > WAVE) return MARL_EUNSUPPORTED;
-    hipLaunchKernelGGL(jam_bits_kernel, dim3(E), dim3(WAVE), sizeof(WaveLds), (hipStream_t)stream, *p, x, y, band,
+    hipLaunchKernelGGL(jam_bits_kernel, dim3(E), dim3(WAVE), wave_lds_bytes(p->N), (hipStream_t)stream, *p, x, y, band,
                        jam_x, jam_y, jam_band, bits);
     return hip_check(hipGetLastError());
 }
@@ -1010,9 +1124,8 @@ int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t* bits, double* l
                            void* stream) {
     if (N < 1 || E < 1 || !bits || !lambda2) return MARL_EINVAL;
     if (N > WAVE) return MARL_EUNSUPPORTED;
-    if (rounds <= 0) rounds = 7;
-    hipLaunchKernelGGL(lambda2_bits_kernel, dim3(E), dim3(WAVE), wave_lds_bytes(N), (hipStream_t)stream, (int)N,
-                       bits, lambda2, (int)rounds);
+    if (rounds <= 0) rounds = 8;
+    MARL_DISPATCH_NPAD(N, lambda2_bits_kernel, dim3(E), wave_lds_bytes(N), stream, (int)N, bits, lambda2, (int)rounds);
     return hip_check(hipGetLastError());
 }
 
@@ -1024,7 +1137,7 @@ int marl_dbscan(const MarlEnvParams* p, int32_t E, const double* x, const double
     if (E < 1 || !x || !y || !labels || !cent_x || !cent_y || !cent_size || !n_clusters || !ncent)
         return MARL_EINVAL;
     if (p->N > WAVE) return MARL_EUNSUPPORTED;
-    hipLaunchKernelGGL(dbscan_kernel, dim3(E), dim3(WAVE), sizeof(WaveLds), (hipStream_t)stream, *p, x, y, labels,
+    hipLaunchKernelGGL(dbscan_kernel, dim3(E), dim3(WAVE), wave_lds_bytes(p->N), (hipStream_t)stream, *p, x, y, labels,
                        cent_x, cent_y, cent_size, n_clusters, ncent);
     return hip_check(hipGetLastError());
 }
