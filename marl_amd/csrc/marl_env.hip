@@ -111,6 +111,7 @@ struct WaveLds {
     double jx[WAVE], jy[WAVE];        // jammer positions
     double2 uq[WAVE];                 // Householder vectors (u_c, q_c) interleaved for one 16-byte broadcast read
     double dd[WAVE], e2[WAVE];        // tridiagonal: diagonal, squared off-diagonal
+    __attribute__((aligned(16))) double urow[WAVE];   // pivot row of the current Householder step
     unsigned long long xfer[WAVE];    // lane-to-lane hand-over of 64-bit rows
     double cx[WAVE + 2], cy[WAVE + 2];  // centroids in dict order
     double px[WAVE + 2], py[WAVE + 2];  // previous centroids
@@ -207,8 +208,10 @@ struct ColBlocks {
             ColBlocks<NPAD, B + 1>::matvec(a, uj, l, p0, p1);
         }
     }
-    // A[:, c] -= u q_c + q u_c; (u_c, q_c) by one 16-byte broadcast LDS read per column
-    static __device__ __forceinline__ void update(double (&a)[NPAD], double uj, double qj, int l, const double2* uq) {
+    // A[:, c] -= u q_c + q u_c; (u_c, q_c) by one 16-byte broadcast LDS read per column.
+    // Lane l (the next pivot) also copies its updated row to urow for the next step.
+    static __device__ __forceinline__ void update(double (&a)[NPAD], double uj, double qj, int lane, int l,
+                                                  const double2* uq, double* urow) {
         if constexpr (B * 8 < NPAD) {
             if (B * 8 > l) return;
             static_for<0, 8>([&](auto k) {
@@ -216,29 +219,34 @@ struct ColBlocks {
                 const double2 t = uq[c];
                 a[c] = fma(-uj, t.y, fma(-qj, t.x, a[c]));
             });
+            if (lane == l) {
+                static_for<0, 4>([&](auto k) {
+                    constexpr int c = B * 8 + 2 * decltype(k)::value;
+                    *reinterpret_cast<double2*>(urow + c) = make_double2(a[c], a[c + 1]);
+                });
+            }
             // pin this block's results here: without it the compiler issues every block's loads
             // first and sinks all the arithmetic behind them, which needs 4 registers per column
             asm volatile("" : "+v"(a[B * 8]), "+v"(a[B * 8 + 1]), "+v"(a[B * 8 + 2]), "+v"(a[B * 8 + 3]),
                               "+v"(a[B * 8 + 4]), "+v"(a[B * 8 + 5]), "+v"(a[B * 8 + 6]), "+v"(a[B * 8 + 7])
                          :: "memory");
-            ColBlocks<NPAD, B + 1>::update(a, uj, qj, l, uq);
+            ColBlocks<NPAD, B + 1>::update(a, uj, qj, lane, l, uq, urow);
+        }
+    }
+    // lane `src` writes columns 0..l (rounded up to the block) of its row to urow
+    static __device__ __forceinline__ void dump_row(const double (&a)[NPAD], int lane, int src, int l, double* urow) {
+        if constexpr (B * 8 < NPAD) {
+            if (B * 8 > l) return;
+            if (lane == src) {
+                static_for<0, 4>([&](auto k) {
+                    constexpr int c = B * 8 + 2 * decltype(k)::value;
+                    *reinterpret_cast<double2*>(urow + c) = make_double2(a[c], a[c + 1]);
+                });
+            }
+            ColBlocks<NPAD, B + 1>::dump_row(a, lane, src, l, urow);
         }
     }
 };
-
-// a[i] for a wave-uniform runtime i in [LO, HI): binary search by uniform branches
-template <int NPAD, int LO, int HI>
-__device__ __forceinline__ double column_of(const double (&a)[NPAD], int i) {
-    if constexpr (HI - LO == 1) {
-        double v = a[LO];
-        asm volatile("" : "+v"(v));      // opaque leaf: stops the compiler from rebuilding a dynamic a[i] (scratch array)
-        return v;
-    } else {
-        constexpr int MID = (LO + HI) / 2;
-        if (i < MID) return column_of<NPAD, LO, MID>(a, i);
-        return column_of<NPAD, MID, HI>(a, i);
-    }
-}
 
 // Second-smallest eigenvalue of L = D - A for the graph whose adjacency rows are
 // `row` (communication_graph.py:184-286; the reference calls LAPACK dsyevr through
@@ -292,35 +300,40 @@ __device__ __forceinline__ double lambda2_wave(uint64_t row, int n, int lane, Wa
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
 
-    double a[NPAD];
+    double a[NPAD];                                   // row `lane` of the matrix
     static_for<0, NPAD>([&](auto k) {
         constexpr int c = decltype(k)::value;
         a[c] = (c == lane) ? (double)cdeg : -(double)((crow >> c) & 1ull);
     });
 
+    // Row i of the symmetric matrix is also its column i: the pivot lane publishes its row in
+    // LDS (static register indices) and lane j picks element j.
+    ColBlocks<NPAD, 0>::dump_row(a, lane, np - 1, np - 1, L.urow);
+    WSYNC();
     for (int i = np - 1; i >= 2; --i) {
         const int l = i - 1;
-        const double col = column_of<NPAD, 0, NPAD>(a, i);     // A[lane][i] == A[i][lane]
-        const double aii = readlane_d(col, i);
+        const double col = L.urow[lane];                         // A[i][lane]
+        const double aii = L.urow[i];
         double uj = (lane <= l) ? col : 0.0;
         double h = wave_sum_dpp(uj * uj);
         if (lane == 0) { L.dd[i] = aii; L.e2[i] = h; }
-        if (h == 0.0) continue;                         // row already reduced
+        // h == 0 (row already reduced): u = 0 and 1/h := 0 turn the step into a no-op that still
+        // hands the next pivot row over
         const double f = readlane_d(uj, l);
         const double g = (f >= 0.0) ? -sqrt(h) : sqrt(h);
-        h -= f * g;
+        const double h2 = h - f * g;
         if (lane == l) uj = f - g;
         // p = A u / h : u_c reaches every lane through SGPRs
         double p0 = 0.0, p1 = 0.0;
         ColBlocks<NPAD, 0>::matvec(a, uj, l, p0, p1);
-        const double hinv = 1.0 / h;
+        const double hinv = (h > 0.0) ? 1.0 / h2 : 0.0;
         const double p = (lane <= l) ? (p0 + p1) * hinv : 0.0;
         const double K = wave_sum_dpp(uj * p) * (0.5 * hinv);
         const double qj = (lane <= l) ? fma(-K, uj, p) : 0.0;
         L.uq[lane] = make_double2(uj, qj);
         WSYNC();
         // A -= u q^T + q u^T : (u_c, q_c) by one broadcast LDS read per column
-        ColBlocks<NPAD, 0>::update(a, uj, qj, l, L.uq);
+        ColBlocks<NPAD, 0>::update(a, uj, qj, lane, l, L.uq, L.urow);
         WSYNC();
     }
     {
