@@ -1,0 +1,432 @@
+"""Actor / Critic networks and the batched PPO agent.
+
+Same architecture, initialisation, losses and quirks as the reference
+(agents/actor.py:86-116, agents/critic.py:71-91, agents/ppo_agent.py:193-373);
+the two MLPs stay stock PyTorch (36 k parameters: nothing to write a kernel
+for).  What changes is the data path: observations, actions, rewards and
+values never leave the GPU, E environments are acted on at once, the rollout
+lives in `DeviceRolloutBuffer`, GAE runs in libmarl_env.so, and with more than
+one rank the gradients of both networks travel in ONE flat all-reduce per
+optimiser step (RCCL over xGMI; 145 KB, latency bound).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.distributions import Categorical, Normal
+
+from . import _lib
+
+
+class Actor(nn.Module):
+    """agents/actor.py:56-247: 5 -> hidden -> hidden (LayerNorm + ReLU) trunk, heads for
+    velocity mean (2), clamped log-std (2) and band logits (num_bands)."""
+
+    def __init__(self, obs_dim=5, hidden_dim=128, v_max=5.0, num_bands=4, log_std_min=-2.0, log_std_max=2.0):
+        super().__init__()
+        self.obs_dim, self.hidden_dim, self.v_max, self.num_bands = obs_dim, hidden_dim, v_max, num_bands
+        self.log_std_min, self.log_std_max = log_std_min, log_std_max
+        self.trunk = nn.Sequential(nn.Linear(obs_dim, hidden_dim), nn.LayerNorm(hidden_dim), nn.ReLU(),
+                                   nn.Linear(hidden_dim, hidden_dim), nn.LayerNorm(hidden_dim), nn.ReLU())
+        self.mu_head = nn.Linear(hidden_dim, 2)
+        self.log_std_head = nn.Linear(hidden_dim, 2)
+        self.band_head = nn.Linear(hidden_dim, num_bands)
+        for m in self.modules():                                    # actor.py:105-116
+            if isinstance(m, nn.Linear):
+                nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
+                nn.init.constant_(m.bias, 0.0)
+        nn.init.orthogonal_(self.mu_head.weight, gain=0.01)
+        nn.init.orthogonal_(self.log_std_head.weight, gain=0.01)
+        nn.init.constant_(self.log_std_head.bias, -0.5)
+        nn.init.orthogonal_(self.band_head.weight, gain=0.01)
+
+    def forward(self, obs):
+        f = self.trunk(obs)
+        return self.mu_head(f), torch.clamp(self.log_std_head(f), self.log_std_min, self.log_std_max), self.band_head(f)
+
+    def sample(self, obs, deterministic=False, generator: Optional[torch.Generator] = None):
+        """actor.py:146-202.  obs [..., obs_dim] -> actions [..., 3], log_prob [...], entropy [...]."""
+        mu, log_std, logits = self.forward(obs)
+        std = torch.exp(log_std)
+        vdist, bdist = Normal(mu, std), Categorical(logits=logits)
+        if deterministic:
+            velocity, band = mu, torch.argmax(logits, dim=-1)
+        else:
+            if generator is None:
+                velocity, band = vdist.rsample(), bdist.sample()
+            else:
+                velocity = mu + std * torch.randn(mu.shape, device=mu.device, dtype=mu.dtype, generator=generator)
+                band = torch.multinomial(bdist.probs.reshape(-1, self.num_bands), 1,
+                                         generator=generator).reshape(logits.shape[:-1])
+        log_prob = vdist.log_prob(velocity).sum(dim=-1) + bdist.log_prob(band)
+        entropy = vdist.entropy().sum(dim=-1) + bdist.entropy()
+        actions = torch.cat([torch.clamp(velocity, -self.v_max, self.v_max), band.unsqueeze(-1).float()], dim=-1)
+        return actions, log_prob, entropy
+
+    def evaluate_actions(self, obs, actions):
+        """actor.py:204-247."""
+        mu, log_std, logits = self.forward(obs)
+        vdist, bdist = Normal(mu, torch.exp(log_std)), Categorical(logits=logits)
+        velocity = torch.clamp(actions[..., :2], -self.v_max * 2, self.v_max * 2)
+        band = actions[..., 2].long()
+        log_prob = vdist.log_prob(velocity).sum(dim=-1) + bdist.log_prob(band)
+        entropy = vdist.entropy().sum(dim=-1) + bdist.entropy()
+        return log_prob, entropy
+
+
+class Critic(nn.Module):
+    """agents/critic.py:53-134: 5 -> hidden -> hidden -> 1 on the mean-pooled observation."""
+
+    def __init__(self, obs_dim=5, hidden_dim=128):
+        super().__init__()
+        self.obs_dim, self.hidden_dim = obs_dim, hidden_dim
+        self.network = nn.Sequential(nn.Linear(obs_dim, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, hidden_dim),
+                                     nn.ReLU(), nn.Linear(hidden_dim, 1))
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
+                nn.init.constant_(m.bias, 0.0)
+        nn.init.orthogonal_(self.network[-1].weight, gain=1.0)
+
+    def forward(self, obs):
+        if obs.dim() == 3:
+            obs = obs.mean(dim=1)
+        elif obs.dim() == 1:
+            obs = obs.unsqueeze(0)
+        return self.network(obs)
+
+    def forward_pooled(self, obs_pooled):
+        return self.network(obs_pooled)
+
+
+class DeviceRolloutBuffer:
+    """RolloutBuffer (agents/rollout_buffer.py:38-279) for E environments, resident on the GPU.
+
+    Layout [T, E, M, .]: slot t of `observations`, `rewards`, `dones` can be handed to
+    `BatchedJammerEnv.step(out_obs=..., out_reward=..., out_truncated=...)` so that the step
+    kernel writes the transition in place.  `compute_returns_and_advantages` runs the
+    reference's reverse GAE scan (one lane per env, marl_gae) and its whole-buffer
+    advantage normalisation, summed over all ranks when torch.distributed is initialised.
+    """
+
+    def __init__(self, buffer_size, num_envs, M=4, obs_dim=5, action_dim=3, gamma=0.99, gae_lambda=0.95,
+                 device="cuda"):
+        self.buffer_size, self.E, self.M = buffer_size, num_envs, M
+        self.obs_dim, self.action_dim, self.gamma, self.gae_lambda = obs_dim, action_dim, gamma, gae_lambda
+        self.device = torch.device(device)
+        T, E = buffer_size, num_envs
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.device)
+        self.observations = z(T + 1, E, M, obs_dim)      # slot t+1 = observation after step t
+        self.actions = z(T, E, M, action_dim)
+        self.log_probs = z(T, E, M)
+        self.rewards = z(T, E)
+        self.dones_u8 = z(T, E, dt=torch.uint8)
+        self.values = z(T, E)
+        self.advantages = z(T, E)
+        self.returns = z(T, E)
+        self.pos, self.full, self.generator = 0, False, 0
+
+    def reset(self):
+        self.pos, self.full = 0, False
+        self.generator += 1
+
+    def __len__(self):
+        return self.buffer_size if self.full else self.pos
+
+    @property
+    def size(self):
+        return len(self)
+
+    def add(self, obs, actions, log_probs, reward, done, value):
+        """Copying form of rollout_buffer.py:120-149 (the in-place form is `slot`)."""
+        t = self.pos
+        self.observations[t].copy_(torch.as_tensor(obs, device=self.device).reshape(self.E, self.M, self.obs_dim))
+        self.actions[t].copy_(torch.as_tensor(actions, device=self.device).reshape(self.E, self.M, self.action_dim))
+        self.log_probs[t].copy_(torch.as_tensor(log_probs, device=self.device).reshape(self.E, self.M))
+        self.rewards[t].copy_(torch.as_tensor(reward, device=self.device, dtype=torch.float32).reshape(self.E))
+        self.dones_u8[t].copy_(torch.as_tensor(done, device=self.device).reshape(self.E).to(torch.uint8))
+        self.values[t].copy_(torch.as_tensor(value, device=self.device, dtype=torch.float32).reshape(self.E))
+        self.advance()
+
+    def slot(self):
+        """Views of the current slot for in-place writes: (obs_in, actions, log_probs, values,
+        reward_out, done_out, obs_out)."""
+        t = self.pos
+        return (self.observations[t], self.actions[t], self.log_probs[t], self.values[t], self.rewards[t],
+                self.dones_u8[t], self.observations[t + 1])
+
+    def advance(self):
+        self.pos += 1
+        if self.pos == self.buffer_size:
+            self.full = True
+
+    def compute_returns_and_advantages(self, last_values: torch.Tensor, last_dones: torch.Tensor):
+        """rollout_buffer.py:151-209 per env; normalisation over the whole buffer of all ranks."""
+        T = len(self)
+        lib = _lib.load()
+        dones = self.dones_u8[:T].float().contiguous()
+        lv = last_values.to(self.device, torch.float32).reshape(self.E).contiguous()
+        ld = last_dones.to(self.device).float().reshape(self.E).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.marl_gae(T, self.E, self.rewards.data_ptr(), self.values.data_ptr(), dones.data_ptr(),
+                                    lv.data_ptr(), ld.data_ptr(), float(self.gamma), float(self.gae_lambda),
+                                    self.advantages.data_ptr(), self.returns.data_ptr(),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "marl_gae")
+        self.advantages[:T] = normalise_advantages(self.advantages[:T])
+
+    def get_samples(self):
+        """rollout_buffer.py:211-229: flattened (T*E*M, .) views; advantage / return / value are
+        shared by the M agents of an env."""
+        T, E, M = len(self), self.E, self.M
+        obs = self.observations[:T].reshape(-1, self.obs_dim)
+        actions = self.actions[:T].reshape(-1, self.action_dim)
+        log_probs = self.log_probs[:T].reshape(-1)
+        adv = self.advantages[:T].unsqueeze(-1).expand(T, E, M).reshape(-1)
+        ret = self.returns[:T].unsqueeze(-1).expand(T, E, M).reshape(-1)
+        val = self.values[:T].unsqueeze(-1).expand(T, E, M).reshape(-1)
+        return obs, actions, log_probs, adv, ret, val
+
+
+def _dist_on() -> bool:
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
+def normalise_advantages(adv: torch.Tensor) -> torch.Tensor:
+    """(A - mean) / (std + 1e-8) with population std over the whole buffer
+    (rollout_buffer.py:207-209), the moments summed over every rank."""
+    stats = torch.stack([adv.sum(dtype=torch.float64), (adv.double() ** 2).sum(),
+                         torch.tensor(float(adv.numel()), dtype=torch.float64, device=adv.device)])
+    if _dist_on():
+        torch.distributed.all_reduce(stats)
+    mean = stats[0] / stats[2]
+    var = torch.clamp(stats[1] / stats[2] - mean * mean, min=0.0)
+    return ((adv - mean.float()) / (torch.sqrt(var).float() + 1e-8))
+
+
+class FlatGradSync:
+    """One all-reduce for the gradients of several modules: grads are packed into a single
+    flat float32 buffer, summed across ranks, divided by the world size and unpacked."""
+
+    def __init__(self, modules):
+        self.params = [p for m in modules for p in m.parameters() if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = None
+
+    def sync(self):
+        if not _dist_on() or torch.distributed.get_world_size() == 1:
+            return
+        dev = self.params[0].device
+        if self.flat is None or self.flat.device != dev:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        o = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                self.flat[o:o + n].zero_()
+            else:
+                self.flat[o:o + n].copy_(p.grad.reshape(-1))
+            o += n
+        torch.distributed.all_reduce(self.flat)
+        self.flat.div_(torch.distributed.get_world_size())
+        o = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            p.grad.copy_(self.flat[o:o + n].view_as(p))
+            o += n
+
+
+class PPOAgent:
+    """PPOAgent of the reference (agents/ppo_agent.py:66-484) acting on E environments at once.
+
+    get_action(obs [E,M,5]) -> (actions [E,M,3], log_probs [E,M], values [E]) as device tensors;
+    a numpy (M,5) observation is treated as a batch of one and returns numpy / float exactly
+    like the reference.  update(last_obs, last_done) runs the reference's clipped-surrogate
+    loop with its quirks kept: critic on per-agent observations during the update
+    (ppo_agent.py:301), two optimisers, grad-norm clip 0.5 each, KL early stop at 0.03.
+    """
+
+    def __init__(self, obs_dim=5, hidden_dim=128, M=4, v_max=5.0, num_bands=4, log_std_min=-1.0, log_std_max=0.5,
+                 gamma=0.99, gae_lambda=0.95, clip_eps=0.2, lr_actor=3e-4, lr_critic=1e-3, c1=0.5, c2=0.01,
+                 max_grad_norm=0.5, rollout_length=2048, batch_size=256, n_epochs=10, device="auto", num_envs=1,
+                 seed: Optional[int] = None):
+        self.obs_dim, self.hidden_dim, self.M, self.v_max, self.num_bands = obs_dim, hidden_dim, M, v_max, num_bands
+        self.gamma, self.gae_lambda, self.clip_eps, self.c1, self.c2 = gamma, gae_lambda, clip_eps, c1, c2
+        self.c2_initial, self.max_grad_norm = c2, max_grad_norm
+        self.lr_actor_initial, self.lr_critic_initial = lr_actor, lr_critic
+        self.rollout_length, self.batch_size, self.n_epochs, self.E = rollout_length, batch_size, n_epochs, num_envs
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu") if device == "auto" \
+            else torch.device(device)
+        if seed is not None:
+            torch.manual_seed(seed)
+        self.actor = Actor(obs_dim, hidden_dim, v_max, num_bands, log_std_min, log_std_max).to(self.device)
+        self.critic = Critic(obs_dim, hidden_dim).to(self.device)
+        if _dist_on():                       # every rank starts from rank 0's weights
+            for p in list(self.actor.parameters()) + list(self.critic.parameters()):
+                torch.distributed.broadcast(p.data, src=0)
+        self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=lr_actor)
+        self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr=lr_critic)
+        self._sync = FlatGradSync([self.actor, self.critic])
+        self.buffer = None
+        if self.device.type == "cuda":
+            self.buffer = DeviceRolloutBuffer(rollout_length, num_envs, M, obs_dim, 3, gamma, gae_lambda, self.device)
+        self.total_timesteps, self.total_updates = 0, 0
+        self.training_stats: Dict[str, List[float]] = {k: [] for k in
+                                                       ("actor_loss", "critic_loss", "entropy", "clip_fraction",
+                                                        "approx_kl")}
+        self.target_kl = 0.03                                  # ppo_agent.py:284
+        self._sample_gen = None
+
+    # -- acting (ppo_agent.py:193-225) ----------------------------------------
+    @torch.no_grad()
+    def get_action(self, obs, deterministic: bool = False):
+        single = isinstance(obs, np.ndarray)
+        o = torch.from_numpy(obs).float().to(self.device) if single else obs
+        if o.dim() == 2:
+            o = o.unsqueeze(0)
+        actions, log_probs, _ = self.actor.sample(o, deterministic, generator=self._sample_gen)
+        values = self.critic.forward_pooled(o.mean(dim=1)).squeeze(-1)
+        if single:
+            return actions[0].cpu().numpy(), log_probs[0].cpu().numpy(), float(values[0].item())
+        return actions, log_probs, values
+
+    def store_transition(self, obs, actions, log_probs, reward, done, value):
+        """ppo_agent.py:227-248 (copying form)."""
+        self.buffer.add(obs, actions, log_probs, reward, done, value)
+        self.total_timesteps += self.E
+
+    @torch.no_grad()
+    def act_into_buffer(self, obs: Optional[torch.Tensor] = None):
+        """Acts on buffer slot t's observation and writes actions / log-probs / values in place;
+        returns (actions, reward_out, done_out, next_obs_out) for BatchedJammerEnv.step."""
+        obs_in, act, logp, val, rew, done, obs_out = self.buffer.slot()
+        if obs is not None and obs.data_ptr() != obs_in.data_ptr():
+            obs_in.copy_(obs)
+        a, lp, v = self.get_action(obs_in)
+        act.copy_(a); logp.copy_(lp); val.copy_(v)
+        return act, rew, done, obs_out
+
+    def commit_step(self):
+        self.buffer.advance()
+        self.total_timesteps += self.E
+
+    # -- learning (ppo_agent.py:250-373) ----------------------------------------
+    def update(self, last_obs, last_done) -> Dict[str, float]:
+        with torch.no_grad():
+            lo = torch.from_numpy(last_obs).float().to(self.device) if isinstance(last_obs, np.ndarray) else last_obs
+            if lo.dim() == 2:
+                lo = lo.unsqueeze(0)
+            last_value = self.critic.forward_pooled(lo.mean(dim=1)).squeeze(-1)
+            ld = torch.as_tensor(last_done, device=self.device).reshape(-1).expand(self.E) \
+                if not isinstance(last_done, torch.Tensor) else last_done
+        self.buffer.compute_returns_and_advantages(last_value, ld)
+        obs, actions, logp, adv, ret, _ = self.buffer.get_samples()
+        stats = self.optimise(obs, actions, logp, adv, ret)
+        self.total_updates += 1
+        self.buffer.reset()
+        for k, v in stats.items():
+            self.training_stats[k].append(v)
+        return stats
+
+    def optimise(self, obs, actions, old_log_probs, advantages, returns, generator=None) -> Dict[str, float]:
+        """The epoch / minibatch loop of ppo_agent.py:286-354 on flattened device tensors.  Works on
+        any device; with torch.distributed initialised, gradients are averaged in one flat
+        all-reduce per step and the epoch KL is averaged so that every rank stops together."""
+        n = obs.shape[0]
+        keys = ("actor_loss", "critic_loss", "entropy", "clip_fraction", "approx_kl")
+        acc = torch.zeros(len(keys), dtype=torch.float64, device=obs.device)
+        steps = 0
+        for epoch in range(self.n_epochs):
+            perm = torch.randperm(n, device=obs.device, generator=generator)
+            epoch_kl = torch.zeros((), dtype=torch.float64, device=obs.device)
+            nb = 0
+            for s in range(0, n, self.batch_size):
+                idx = perm[s:s + self.batch_size]
+                b_obs, b_act = obs[idx], actions[idx]
+                b_old, b_adv, b_ret = old_log_probs[idx], advantages[idx], returns[idx]
+                log_probs, entropy = self.actor.evaluate_actions(b_obs, b_act)
+                values = self.critic.forward_pooled(b_obs).squeeze(-1)
+                ratio = torch.exp(log_probs - b_old)
+                surr1 = ratio * b_adv
+                surr2 = torch.clamp(ratio, 1 - self.clip_eps, 1 + self.clip_eps) * b_adv
+                actor_loss = -torch.min(surr1, surr2).mean()
+                critic_loss = self.c1 * ((values - b_ret) ** 2).mean()
+                entropy_loss = -self.c2 * entropy.mean()
+                self.actor_optimizer.zero_grad(set_to_none=False)
+                self.critic_optimizer.zero_grad(set_to_none=False)
+                (actor_loss + entropy_loss).backward()
+                critic_loss.backward()
+                self._sync.sync()
+                nn.utils.clip_grad_norm_(self.actor.parameters(), self.max_grad_norm)
+                nn.utils.clip_grad_norm_(self.critic.parameters(), self.max_grad_norm)
+                self.actor_optimizer.step()
+                self.critic_optimizer.step()
+                with torch.no_grad():
+                    kl = ((ratio - 1) - torch.log(ratio)).mean()
+                    acc += torch.stack([actor_loss, critic_loss, entropy.mean(),
+                                        (torch.abs(ratio - 1) > self.clip_eps).float().mean(), kl]).double()
+                    epoch_kl += kl.double()
+                nb += 1
+                steps += 1
+            avg_kl = epoch_kl / max(nb, 1)
+            if _dist_on():
+                torch.distributed.all_reduce(avg_kl)
+                avg_kl = avg_kl / torch.distributed.get_world_size()
+            if float(avg_kl) > self.target_kl:
+                break
+        mean = (acc / max(steps, 1))
+        if _dist_on():
+            torch.distributed.all_reduce(mean)
+            mean = mean / torch.distributed.get_world_size()
+        return {k: float(v) for k, v in zip(keys, mean.cpu())}
+
+    # -- schedule / mode / checkpoint (ppo_agent.py:375-484) ----------------------
+    def set_learning_rate(self, lr_actor, lr_critic):
+        for g in self.actor_optimizer.param_groups:
+            g["lr"] = lr_actor
+        for g in self.critic_optimizer.param_groups:
+            g["lr"] = lr_critic
+
+    def set_entropy_coef(self, c2):
+        self.c2 = c2
+
+    def set_training_mode(self, training=True):
+        self.actor.train(training)
+        self.critic.train(training)
+
+    def _config(self):
+        return {k: getattr(self, k) for k in ("obs_dim", "hidden_dim", "M", "v_max", "num_bands", "gamma",
+                                              "gae_lambda", "clip_eps", "c1", "c2", "max_grad_norm",
+                                              "rollout_length", "batch_size", "n_epochs")}
+
+    def save(self, path):
+        """Same file name and keys as the reference checkpoint (ppo_agent.py:386-420)."""
+        path = Path(path)
+        path.mkdir(parents=True, exist_ok=True)
+        torch.save({"actor_state_dict": self.actor.state_dict(), "critic_state_dict": self.critic.state_dict(),
+                    "actor_optimizer_state_dict": self.actor_optimizer.state_dict(),
+                    "critic_optimizer_state_dict": self.critic_optimizer.state_dict(),
+                    "total_timesteps": self.total_timesteps, "total_updates": self.total_updates,
+                    "training_stats": self.training_stats, "config": self._config()}, path / "ppo_agent.pt")
+
+    def load(self, path):
+        ck = torch.load(Path(path) / "ppo_agent.pt", map_location=self.device, weights_only=True)
+        self.actor.load_state_dict(ck["actor_state_dict"])
+        self.critic.load_state_dict(ck["critic_state_dict"])
+        self.actor_optimizer.load_state_dict(ck["actor_optimizer_state_dict"])
+        self.critic_optimizer.load_state_dict(ck["critic_optimizer_state_dict"])
+        self.total_timesteps, self.total_updates = ck["total_timesteps"], ck["total_updates"]
+        self.training_stats = ck["training_stats"]
+
+    @classmethod
+    def from_checkpoint(cls, path, device="auto", num_envs=1):
+        ck = torch.load(Path(path) / "ppo_agent.pt", map_location="cpu", weights_only=True)
+        agent = cls(device=device, num_envs=num_envs, **ck["config"])
+        agent.load(path)
+        return agent

@@ -1,0 +1,146 @@
+"""CPU tests of the agent side (pure torch): network shapes / parameter counts of the
+reference architecture, the PPO optimise loop, checkpoint round trip, and the multi-rank
+path (flat gradient all-reduce, cross-rank advantage normalisation, common KL early stop)
+with two gloo processes."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from marl_amd.agents import Actor, Critic, FlatGradSync, PPOAgent, normalise_advantages
+
+
+def test_parameter_counts_match_reference_architecture():
+    # actor 768+256+16512+256+258+258+516 = 18824 (agents/actor.py:86-100); critic 17409 (critic.py:71-77)
+    assert sum(p.numel() for p in Actor().parameters()) == 18824
+    assert sum(p.numel() for p in Critic().parameters()) == 17409
+
+
+def test_actor_sample_and_evaluate_shapes():
+    torch.manual_seed(0)
+    a = Actor(log_std_min=-1.0, log_std_max=0.5)
+    obs = torch.rand(7, 4, 5)
+    act, logp, ent = a.sample(obs)
+    assert act.shape == (7, 4, 3) and logp.shape == (7, 4) and ent.shape == (7, 4)
+    assert act[..., :2].abs().max() <= 5.0 and set(act[..., 2].unique().tolist()) <= {0.0, 1.0, 2.0, 3.0}
+    lp2, ent2 = a.evaluate_actions(obs.reshape(-1, 5), act.reshape(-1, 3))
+    clamped = act[..., :2].abs().max(dim=-1).values.reshape(-1) >= 5.0
+    assert torch.allclose(lp2[~clamped], logp.reshape(-1)[~clamped], atol=1e-5)
+    det, _, _ = a.sample(obs, deterministic=True)
+    det2, _, _ = a.sample(obs, deterministic=True)
+    assert torch.equal(det, det2)
+    c = Critic()
+    assert c.forward_pooled(obs.mean(dim=1)).shape == (7, 1) and c(obs).shape == (7, 1)
+
+
+def _fake_rollout(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.rand(n, 5, generator=g)
+    act = torch.cat([torch.randn(n, 2, generator=g) * 2, torch.randint(0, 4, (n, 1), generator=g).float()], dim=1)
+    old = torch.randn(n, generator=g) * 0.1 - 3.0
+    adv = torch.randn(n, generator=g)
+    ret = torch.randn(n, generator=g)
+    return obs, act, old, adv, ret
+
+
+def test_optimise_runs_and_improves_value_fit():
+    agent = PPOAgent(device="cpu", batch_size=64, n_epochs=4, seed=3)
+    obs, act, old, adv, ret = _fake_rollout(512, 1)
+    with torch.no_grad():
+        old = agent.actor.evaluate_actions(obs, act)[0]
+        before = ((agent.critic.forward_pooled(obs).squeeze(-1) - ret) ** 2).mean().item()
+    stats = agent.optimise(obs, act, old, adv, ret)
+    assert set(stats) == {"actor_loss", "critic_loss", "entropy", "clip_fraction", "approx_kl"}
+    assert all(np.isfinite(v) for v in stats.values())
+    with torch.no_grad():
+        after = ((agent.critic.forward_pooled(obs).squeeze(-1) - ret) ** 2).mean().item()
+    assert after < before
+
+
+def test_numpy_single_env_api_and_checkpoint_roundtrip(tmp_path):
+    agent = PPOAgent(device="cpu", M=4, seed=0)
+    obs = np.random.RandomState(0).rand(4, 5).astype(np.float32)
+    a, lp, v = agent.get_action(obs)
+    assert a.shape == (4, 3) and lp.shape == (4,) and isinstance(v, float)
+    agent.total_timesteps, agent.total_updates = 123, 4
+    agent.save(tmp_path / "ck")
+    other = PPOAgent.from_checkpoint(tmp_path / "ck", device="cpu")
+    assert other.total_timesteps == 123 and other.total_updates == 4
+    for p, q in zip(agent.actor.parameters(), other.actor.parameters()):
+        assert torch.equal(p, q)
+    d1, _, _ = agent.get_action(obs, deterministic=True)
+    d2, _, _ = other.get_action(obs, deterministic=True)
+    assert np.array_equal(d1, d2)
+
+
+def test_schedule_setters():
+    agent = PPOAgent(device="cpu")
+    agent.set_learning_rate(1e-5, 2e-5)
+    assert agent.actor_optimizer.param_groups[0]["lr"] == 1e-5 and agent.critic_optimizer.param_groups[0]["lr"] == 2e-5
+    agent.set_entropy_coef(0.123)
+    assert agent.c2 == 0.123
+    agent.set_training_mode(False)
+    assert not agent.actor.training
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                      # ranks start different, the agent broadcasts rank 0
+    agent = PPOAgent(device="cpu", batch_size=4096, n_epochs=3)
+    obs, act, old, adv, ret = _fake_rollout(256, 5)
+    half = slice(rank * 128, (rank + 1) * 128)
+    with torch.no_grad():
+        old = agent.actor.evaluate_actions(obs, act)[0]
+    adv_n = normalise_advantages(adv[half] * 3 + 1)    # moments must come from both ranks
+    stats = agent.optimise(obs[half], act[half], old[half], adv[half], ret[half])
+    flat = torch.cat([p.detach().reshape(-1) for p in list(agent.actor.parameters()) + list(agent.critic.parameters())])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        out["params_equal"] = bool(torch.equal(gathered[0], gathered[1]))
+        out["flat"] = flat.clone()
+        out["stats"] = stats
+    out[f"adv{rank}"] = adv_n
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_matches_single_process():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out["params_equal"]
+    # reference: one process, whole batch, same initial weights (seed 100 = rank 0's seed)
+    torch.manual_seed(100)
+    agent = PPOAgent(device="cpu", batch_size=4096, n_epochs=3)
+    obs, act, old, adv, ret = _fake_rollout(256, 5)
+    with torch.no_grad():
+        old = agent.actor.evaluate_actions(obs, act)[0]
+    stats = agent.optimise(obs, act, old, adv, ret)
+    flat = torch.cat([p.detach().reshape(-1) for p in list(agent.actor.parameters()) + list(agent.critic.parameters())])
+    assert torch.allclose(out["flat"], flat, atol=2e-5, rtol=1e-4)
+    for k in stats:
+        assert abs(stats[k] - out["stats"][k]) < 1e-4, k
+    whole = normalise_advantages(adv * 3 + 1)
+    assert torch.allclose(torch.cat([out["adv0"], out["adv1"]]), whole, atol=1e-5)
+
+
+def test_flat_grad_sync_is_noop_without_process_group():
+    m = torch.nn.Linear(3, 2)
+    m(torch.ones(1, 3)).sum().backward()
+    g = m.weight.grad.clone()
+    FlatGradSync([m]).sync()
+    assert torch.equal(m.weight.grad, g)
