@@ -27,6 +27,7 @@
  *   prev_x, prev_y, prev_n_clusters, prev_ncent             DBSCANClusterer._prev_centroids
  *   assign                                 int32  [E][M]    jammer_assignments: cluster id per jammer,
  *                                                            -1 noise pseudo-cluster, -2 none
+ *   workspace                              double [E][ld][ld] scratch of the lambda2 solver, N > 64 only
  */
 #ifndef MARL_ENV_H
 #define MARL_ENV_H
@@ -89,6 +90,7 @@ typedef struct MarlEnvState {
     double *prev_x, *prev_y;
     int32_t *prev_n_clusters, *prev_ncent;
     int32_t *assign;
+    double *workspace;         /* lambda2 scratch, [E][ld][ld] with ld = N rounded up to 8; NULL when N <= 64 */
 } MarlEnvState;
 
 /* Inputs and outputs of one step.  Optional pointers may be NULL. */
@@ -168,7 +170,11 @@ int marl_jam_mask_bits(const MarlEnvParams *p, int32_t E, const double *x, const
 /* compute_laplacian + compute_lambda2 (physics/communication_graph.py:184-286)
  * from adjacency bits [E][N][ceil(N/32)] -> lambda2 [E]. */
 int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t *bits, double *lambda2,
-                           int32_t rounds, void *stream);
+                           int32_t rounds, void *workspace, void *stream);
+
+/* Bytes of device scratch marl_lambda2_from_bits needs (0 for N <= 64; the matrix of the
+ * eigenproblem otherwise).  marl_state_bytes already includes the same amount for the step. */
+size_t marl_lambda2_workspace_bytes(int32_t N, int32_t E);
 
 /* DBSCANClusterer.fit + get_cluster_sizes (clustering/dbscan_clustering.py:78-144)
  * -> labels [E][N], cent_x/cent_y/cent_size [E][N+1], n_clusters/ncent [E]. */

@@ -41,7 +41,7 @@ class MarlEnvParams(C.Structure):
 _STATE_ARRAYS = [
     "enemy_x", "enemy_y", "enemy_vx", "enemy_vy", "jam_x", "jam_y", "jam_band", "last_vx", "last_vy",
     "step_count", "enemy_band", "lambda2_initial", "labels", "cent_x", "cent_y", "cent_size",
-    "n_clusters", "ncent", "prev_x", "prev_y", "prev_n_clusters", "prev_ncent", "assign",
+    "n_clusters", "ncent", "prev_x", "prev_y", "prev_n_clusters", "prev_ncent", "assign", "workspace",
 ]
 
 
@@ -79,7 +79,8 @@ SYMBOLS = {
     "marl_adjacency_bits": (C.c_int, [C.POINTER(MarlEnvParams), C.c_int32, _pd, _pd, _pi, _pu32, C.c_void_p]),
     "marl_jam_mask_bits": (C.c_int, [C.POINTER(MarlEnvParams), C.c_int32, _pd, _pd, _pi, _pd, _pd, _pi, _pu32,
                                      C.c_void_p]),
-    "marl_lambda2_from_bits": (C.c_int, [C.c_int32, C.c_int32, _pu32, _pd, C.c_int32, C.c_void_p]),
+    "marl_lambda2_from_bits": (C.c_int, [C.c_int32, C.c_int32, _pu32, _pd, C.c_int32, C.c_void_p, C.c_void_p]),
+    "marl_lambda2_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "marl_dbscan": (C.c_int, [C.POINTER(MarlEnvParams), C.c_int32, _pd, _pd, _pi, _pd, _pd, _pi, _pi, _pi,
                               C.c_void_p]),
     "marl_gae": (C.c_int, [C.c_int32, C.c_int32, _pf, _pf, _pf, _pf, _pf, C.c_double, C.c_double, _pf, _pf,

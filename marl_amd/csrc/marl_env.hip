@@ -260,41 +260,49 @@ struct ColBlocks {
 //     tridiagonalised by Householder reflections with row j held in the registers of
 //     lane j (no matrix in LDS), then mu_max is bracketed by 64-way multisection on
 //     the sign changes of the Sturm sequence of the tridiagonal matrix.
-template <int NPAD>
-__device__ __forceinline__ double lambda2_wave(uint64_t row, int n, int lane, WaveLds& L, int rounds) {
-    if (n <= 1) return 0.0;
-    const int deg = __popcll(row);
-    const uint64_t active = (n >= 64) ? ~0ull : ((1ull << n) - 1);
-    const uint64_t touched = ballot64(lane < n && deg < n - 1);
-    if (touched == 0) return (double)n;
-    {   // connectivity: breadth-first search from vertex 0
-        uint64_t comp = 1ull, frontier = 1ull;
-        while (frontier) {
-            const uint64_t hit = ballot64((row & frontier) != 0);
-            const uint64_t nw = hit & ~comp;
-            comp |= nw;
-            frontier = nw;
+// Sturm multisection for the largest eigenvalue of the symmetric tridiagonal matrix
+// (L.dd[0..np), L.e2[1..np)) inside [lo, hi]: lane t evaluates the Sturm sequence
+// p_0 = 1, p_k = (d_k - x) p_{k-1} - e_k^2 p_{k-2} at x_t; its sign changes count the
+// eigenvalues below x_t.  Every round shrinks the bracket 65-fold.
+template <class LDS>
+__device__ __forceinline__ double sturm_largest_wave(const LDS& L, int np, int lane, double lo, double hi, int rounds) {
+    for (int r = 0; r < rounds; ++r) {
+        if (hi - lo <= 2e-12 * hi) break;
+        const double w = (hi - lo) * (1.0 / 65.0);
+        const double x = lo + w * (double)(lane + 1);
+        double pm = 1.0, pc = L.dd[0] - x;
+        int cnt = (unsigned)__double2hiint(pc) >> 31;
+        for (int i = 1; i < np; ++i) {
+            const double pn = fma(L.dd[i] - x, pc, -(L.e2[i] * pm));
+            cnt += ((unsigned)(__double2hiint(pn) ^ __double2hiint(pc))) >> 31;
+            pm = pc;
+            pc = pn;
+            if ((i & 7) == 7) {                         // keep the recurrence inside the exponent range
+                const int ex = __builtin_amdgcn_frexp_exp(fabs(pc) > fabs(pm) ? pc : pm);
+                pc = ldexp(pc, -ex);
+                pm = ldexp(pm, -ex);
+            }
         }
-        if (comp != active) return 0.0;
-    }
-    // complement rows restricted to the touched vertices, compacted
-    const int np = __popcll(touched);
-    const uint64_t crow_full = ~row & active & ~(1ull << lane) & touched;
-    uint64_t crow = 0;
-    {
-        uint64_t t = touched;
-        int k = 0;
-        while (t) {
-            const int v = __ffsll((unsigned long long)t) - 1;
-            crow |= ((crow_full >> v) & 1ull) << k;
-            t &= t - 1;
-            ++k;
+        const uint64_t all = ballot64(cnt >= np);
+        if (all == 0) {
+            lo = readlane_d(x, WAVE - 1);
+        } else {
+            const int t = __ffsll((unsigned long long)all) - 1;
+            const double xh = readlane_d(x, t);
+            const double xl = readlane_d(x, t > 0 ? t - 1 : 0);
+            hi = xh;
+            if (t > 0) lo = xl;
         }
     }
-    WSYNC();
-    if ((touched >> lane) & 1ull) L.xfer[__popcll(touched & ((1ull << lane) - 1))] = crow;
-    WSYNC();
-    crow = (lane < np) ? L.xfer[lane] : 0ull;
+    return 0.5 * (lo + hi);
+}
+
+// Largest Laplacian eigenvalue of the graph on np <= NPAD <= 64 vertices whose adjacency
+// rows are `crow` (lane j < np holds row j): Householder tridiagonalisation with row j in
+// the registers of lane j, then Sturm multisection inside the Laplacian bracket
+// [dmax + 1, min(np, 2 dmax)] (valid for a graph with at least one edge).
+template <int NPAD, class LDS>
+__device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int lane, LDS& L, int rounds) {
     const int cdeg = __popcll(crow);
     int dmax = cdeg;
 #pragma unroll
@@ -341,40 +349,56 @@ __device__ __forceinline__ double lambda2_wave(uint64_t row, int n, int lane, Wa
         if (lane == 0) { L.dd[1] = a11; L.e2[1] = a10 * a10; L.dd[0] = a00; L.e2[0] = 0.0; }
     }
     WSYNC();
-    // mu_max in [dmax + 1, min(n', 2 dmax)] (Laplacian bounds for a graph with an edge).
-    // Lane t evaluates the Sturm sequence p_0 = 1, p_k = (d_k - x) p_{k-1} - e_k^2 p_{k-2}
-    // at x_t; its sign changes count the eigenvalues below x_t.
-    double lo = (double)(dmax + 1) * (1.0 - 1e-13) - 1e-13;
-    double hi = (double)min(np, 2 * dmax) * (1.0 + 1e-13) + 1e-13;
-    for (int r = 0; r < rounds; ++r) {
-        if (hi - lo <= 2e-12 * hi) break;
-        const double w = (hi - lo) * (1.0 / 65.0);
-        const double x = lo + w * (double)(lane + 1);
-        double pm = 1.0, pc = L.dd[0] - x;
-        int cnt = (unsigned)__double2hiint(pc) >> 31;
-        for (int i = 1; i < np; ++i) {
-            const double pn = fma(L.dd[i] - x, pc, -(L.e2[i] * pm));
-            cnt += ((unsigned)(__double2hiint(pn) ^ __double2hiint(pc))) >> 31;
-            pm = pc;
-            pc = pn;
-            if ((i & 7) == 7) {                         // keep the recurrence inside the exponent range
-                const int ex = __builtin_amdgcn_frexp_exp(fabs(pc) > fabs(pm) ? pc : pm);
-                pc = ldexp(pc, -ex);
-                pm = ldexp(pm, -ex);
-            }
+    const double lo = (double)(dmax + 1) * (1.0 - 1e-13) - 1e-13;
+    const double hi = (double)min(np, 2 * dmax) * (1.0 + 1e-13) + 1e-13;
+    return sturm_largest_wave(L, np, lane, lo, hi, rounds);
+}
+
+// Second-smallest eigenvalue of L = D - A for the graph whose adjacency rows are
+// `row` (communication_graph.py:184-286; the reference calls LAPACK dsyevr through
+// scipy.linalg.eigh(subset_by_index=[0,1])).
+//
+//   * complete graph -> n, disconnected graph -> 0 (exact, one ballot per BFS level);
+//   * otherwise lambda2(G) = n - mu_max(complement of G): L(G) + L(G') = n I - J, so on
+//     the space orthogonal to the all-ones vector the spectra mirror each other.  Only
+//     the n' vertices that miss at least one neighbour carry edges of the complement;
+//     they are compacted to lanes 0..n'-1 and handed to mu_max_compact_wave.
+template <int NPAD>
+__device__ __forceinline__ double lambda2_wave(uint64_t row, int n, int lane, WaveLds& L, int rounds) {
+    if (n <= 1) return 0.0;
+    const int deg = __popcll(row);
+    const uint64_t active = (n >= 64) ? ~0ull : ((1ull << n) - 1);
+    const uint64_t touched = ballot64(lane < n && deg < n - 1);
+    if (touched == 0) return (double)n;
+    {   // connectivity: breadth-first search from vertex 0
+        uint64_t comp = 1ull, frontier = 1ull;
+        while (frontier) {
+            const uint64_t hit = ballot64((row & frontier) != 0);
+            const uint64_t nw = hit & ~comp;
+            comp |= nw;
+            frontier = nw;
         }
-        const uint64_t all = ballot64(cnt >= np);
-        if (all == 0) {
-            lo = readlane_d(x, WAVE - 1);
-        } else {
-            const int t = __ffsll((unsigned long long)all) - 1;
-            const double xh = readlane_d(x, t);
-            const double xl = readlane_d(x, t > 0 ? t - 1 : 0);
-            hi = xh;
-            if (t > 0) lo = xl;
+        if (comp != active) return 0.0;
+    }
+    // complement rows restricted to the touched vertices, compacted
+    const int np = __popcll(touched);
+    const uint64_t crow_full = ~row & active & ~(1ull << lane) & touched;
+    uint64_t crow = 0;
+    {
+        uint64_t t = touched;
+        int k = 0;
+        while (t) {
+            const int v = __ffsll((unsigned long long)t) - 1;
+            crow |= ((crow_full >> v) & 1ull) << k;
+            t &= t - 1;
+            ++k;
         }
     }
-    return (double)n - 0.5 * (lo + hi);
+    WSYNC();
+    if ((touched >> lane) & 1ull) L.xfer[__popcll(touched & ((1ull << lane) - 1))] = crow;
+    WSYNC();
+    crow = (lane < np) ? L.xfer[lane] : 0ull;
+    return (double)n - mu_max_compact_wave<NPAD>(crow, np, lane, L, rounds);
 }
 
 // ------------------------------------------------------------------ DBSCAN + centroids
@@ -440,7 +464,8 @@ __device__ __forceinline__ int dbscan_wave(const MarlEnvParams& P, int n, int la
 
 // should_reassign_jammers(drift_threshold) (dbscan_clustering.py:163-204) on the
 // current (L.cx..) and previous (L.px..) centroid tables.
-__device__ __forceinline__ bool should_reassign_wave(const MarlEnvParams& P, int lane, const WaveLds& L, int num, int ncent,
+template <class LDS>
+__device__ __forceinline__ bool should_reassign_wave(const MarlEnvParams& P, int lane, const LDS& L, int num, int ncent,
                                      int pnum, int pncent) {
     bool mine = false;
     for (int s = lane; s < ncent; s += WAVE) {
@@ -455,7 +480,8 @@ __device__ __forceinline__ bool should_reassign_wave(const MarlEnvParams& P, int
 }
 
 // assign_jammers_to_clusters(strategy="proportional") (dbscan_clustering.py:263-362) into L.asg.
-__device__ __forceinline__ void assign_proportional_wave(int m, int lane, WaveLds& L, int num, int ncent) {
+template <class LDS>
+__device__ __forceinline__ void assign_proportional_wave(int m, int lane, LDS& L, int num, int ncent) {
     if (lane == 0 && m > 0 && ncent > 0) {
         const int first = 0;
         const int nvalid = (num > 0) ? num : ncent;        // all-noise: the -1 entry is the one cluster
@@ -487,7 +513,8 @@ struct RewardOut { double total; float r0, r1, r2, r3, r4; float o0, o1, o2, o3,
 // RewardCalculator.compute (reward.py:106-306) and ObservationBuilder.build_vectorized
 // (observation.py:264-332).  Lane j < m owns jammer j.  obs_row receives the five
 // features of the lane's jammer.
-__device__ __forceinline__ RewardOut reward_obs_wave(const MarlEnvParams& P, int n, int m, int lane, const WaveLds& L,
+template <class LDS>
+__device__ __forceinline__ RewardOut reward_obs_wave(const MarlEnvParams& P, int n, int m, int lane, const LDS& L,
                                      int eband, int num, int ncent, double lam, double lam0,
                                      float raw_vx, float raw_vy) {
     RewardOut out;
@@ -941,6 +968,727 @@ __global__ void fill_noise_kernel(MarlEnvParams P, MarlEnvState S, uint64_t seed
     noise[((size_t)e * P.N + i) * 2 + 1] = ny;
 }
 
+// ====================================================================== 64 < N <= 256
+// One wavefront still advances one environment, each lane now owning S = ceil(N/64)
+// enemies: enemy i = s*64 + lane lives in slot s of lane (i & 63), and an N-bit row is S
+// 64-bit words, so that word s of a ballot over slot s is exactly word s of a vertex set.
+// The stages are the ones above with a slot loop around them.  lambda2 uses the same
+// complement compaction; with n' <= 64 touched vertices it runs the register-resident
+// solver above, beyond that the n' x n' matrix lives in a caller-provided global workspace
+// (column-major, lane j touches only the rows it owns, so no cross-lane visibility is
+// needed) -- correct, but memory-bound.
+template <int S>
+struct BigLds {
+    static constexpr int NN = WAVE * S;
+    double sx[NN], sy[NN];
+    double jx[WAVE], jy[WAVE];
+    double2 uq[WAVE];
+    double dd[NN], e2[NN];
+    __attribute__((aligned(16))) double urow[WAVE];
+    double uvec[NN], qvec[NN];
+    unsigned long long xfer[NN * S];
+    double cx[NN + 2], cy[NN + 2], px[NN + 2], py[NN + 2];
+    int csz[NN + 2];
+    int lab[NN];
+    int asg[WAVE];
+    int jb[WAVE];
+};
+
+__host__ __device__ inline int big_ld(int n) { return (n + 7) & ~7; }
+
+template <int S>
+__device__ __forceinline__ uint64_t word_mask(int n, int k) {      // valid vertex bits of word k
+    const int cnt = n - k * WAVE;
+    return cnt >= WAVE ? ~0ull : (cnt <= 0 ? 0ull : ((1ull << cnt) - 1));
+}
+
+// rows[s][k]: word k of the row of enemy s*64+lane.  `jam` = false: FSPL adjacency; true: jamming mask.
+template <int S, bool JAM>
+__device__ __forceinline__ void pair_rows_big(uint64_t (&rows)[S][S], const BigLds<S>& L, int n, int m, int lane,
+                                              int eband, double d2max) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = s * WAVE + lane;
+        const double xi = L.sx[i], yi = L.sy[i];
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            uint64_t word = 0;
+            const int cnt = min(WAVE, n - k * WAVE);
+            if constexpr (!JAM) {
+                for (int b = 0; b < cnt; ++b) {
+                    const double dx = xi - L.sx[k * WAVE + b], dy = yi - L.sy[k * WAVE + b];
+                    const double d2 = dx * dx + dy * dy;
+                    word |= (uint64_t)(d2 <= d2max) << b;
+                }
+            } else {
+                for (int q = 0; q < m; ++q) {
+                    if (L.jb[q] != eband) continue;
+                    const double qx = L.jx[q], qy = L.jy[q];
+                    for (int b = 0; b < cnt; ++b) {
+                        const double mx = (xi + L.sx[k * WAVE + b]) / 2, my = (yi + L.sy[k * WAVE + b]) / 2;
+                        const double dx = qx - mx, dy = qy - my;
+                        const double d2 = dx * dx + dy * dy;
+                        word |= (uint64_t)(d2 <= d2max) << b;
+                    }
+                }
+            }
+            if (k == s) word &= ~(1ull << lane);
+            rows[s][k] = (i < n) ? word : 0ull;
+        }
+    }
+}
+
+template <int S>
+__device__ __forceinline__ void store_bits_big(uint32_t* dst, int e, int n, int lane, const uint64_t (&rows)[S][S]) {
+    if (dst == nullptr) return;
+    const int W = (n + 31) / 32;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = s * WAVE + lane;
+        if (i >= n) continue;
+        uint32_t* p = dst + ((size_t)e * n + i) * W;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            if (2 * k < W) p[2 * k] = (uint32_t)rows[s][k];
+            if (2 * k + 1 < W) p[2 * k + 1] = (uint32_t)(rows[s][k] >> 32);
+        }
+    }
+}
+
+template <int S>
+__device__ __forceinline__ bool any_words(const uint64_t (&w)[S]) {
+    uint64_t o = 0;
+#pragma unroll
+    for (int k = 0; k < S; ++k) o |= w[k];
+    return o != 0;
+}
+
+// hit[s] = lanes whose slot-s vertex has a neighbour in `frontier`
+template <int S>
+__device__ __forceinline__ void expand_big(const uint64_t (&rows)[S][S], const uint64_t (&frontier)[S], uint64_t (&hit)[S]) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        uint64_t o = 0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) o |= rows[s][k] & frontier[k];
+        hit[s] = ballot64(o != 0);
+    }
+}
+
+template <int S>
+__device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int n, int lane, BigLds<S>& L, int rounds,
+                                              double* As) {
+    if (n <= 1) return 0.0;
+    uint64_t touched[S];
+    int deg[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        int d = 0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) d += __popcll(rows[s][k]);
+        deg[s] = d;
+        touched[s] = ballot64(s * WAVE + lane < n && d < n - 1);
+    }
+    if (!any_words<S>(touched)) return (double)n;
+    {   // connectivity from vertex 0
+        uint64_t comp[S], frontier[S], hit[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) { comp[k] = 0; frontier[k] = 0; }
+        comp[0] = 1ull; frontier[0] = 1ull;
+        while (any_words<S>(frontier)) {
+            expand_big<S>(rows, frontier, hit);
+#pragma unroll
+            for (int k = 0; k < S; ++k) { const uint64_t nw = hit[k] & ~comp[k]; comp[k] |= nw; frontier[k] = nw; }
+        }
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < S; ++k) all = all && (comp[k] == word_mask<S>(n, k));
+        if (!all) return 0.0;
+    }
+    int np = 0;
+    int before[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) { before[s] = np; np += __popcll(touched[s]); }
+    // compact the complement rows of the touched vertices: bit r of the new row = touched vertex of rank r
+    WSYNC();
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        uint64_t cw[S];
+#pragma unroll
+        for (int q = 0; q < S; ++q) cw[q] = 0;
+        int r = 0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            uint64_t cfull = ~rows[s][k] & word_mask<S>(n, k) & touched[k];
+            if (k == s) cfull &= ~(1ull << lane);
+            uint64_t t = touched[k];
+            while (t) {
+                const int v = __ffsll((unsigned long long)t) - 1;
+                const uint64_t bit = (cfull >> v) & 1ull;
+#pragma unroll
+                for (int q = 0; q < S; ++q) cw[q] |= (((r >> 6) == q) ? bit : 0ull) << (r & 63);
+                t &= t - 1;
+                ++r;
+            }
+        }
+        if ((touched[s] >> lane) & 1ull) {
+            const int rank = before[s] + __popcll(touched[s] & ((1ull << lane) - 1));
+#pragma unroll
+            for (int q = 0; q < S; ++q) L.xfer[rank * S + q] = cw[q];
+        }
+    }
+    WSYNC();
+    if (np <= WAVE) {
+        const uint64_t crow = (lane < np) ? L.xfer[lane * S] : 0ull;
+        return (double)n - mu_max_compact_wave<WAVE>(crow, np, lane, L, rounds);
+    }
+    // ---- n' > 64: matrix in the global workspace, element (r, c) at As[c*ld + r]; lane owns rows r = s*64+lane
+    const int ld = big_ld(n);
+    int dmax = 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int r = s * WAVE + lane;
+        if (r < np) {
+            uint64_t cw[S];
+            int cdeg = 0;
+#pragma unroll
+            for (int q = 0; q < S; ++q) { cw[q] = L.xfer[r * S + q]; cdeg += __popcll(cw[q]); }
+            dmax = max(dmax, cdeg);
+#pragma unroll
+            for (int q = 0; q < S; ++q) {
+                const int cnt = min(WAVE, np - q * WAVE);
+                for (int b = 0; b < cnt; ++b) {
+                    const int c = q * WAVE + b;
+                    As[(size_t)c * ld + r] = (c == r) ? (double)cdeg : -(double)((cw[q] >> b) & 1ull);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
+    for (int i = np - 1; i >= 2; --i) {
+        const int l = i - 1;
+        double u[S], p[S], own_i = 0.0, own_l = 0.0;
+        double hh = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int r = s * WAVE + lane;
+            const double v = (r <= i) ? As[(size_t)i * ld + r] : 0.0;      // A[r][i] == A[i][r]
+            if (r == i) own_i = v;
+            u[s] = (r <= l) ? v : 0.0;
+            if (r == l) own_l = v;
+            hh += u[s] * u[s];
+        }
+        const double h = wave_sum_dpp(hh);
+        const double aii = readlane_d(own_i, i & (WAVE - 1));
+        if (lane == 0) { L.dd[i] = aii; L.e2[i] = h; }
+        const double f = readlane_d(own_l, l & (WAVE - 1));
+        const double g = (f >= 0.0) ? -sqrt(h) : sqrt(h);
+        const double h2 = h - f * g;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int r = s * WAVE + lane;
+            if (r == l) u[s] = f - g;
+            L.uvec[r] = u[s];
+            p[s] = 0.0;
+        }
+        WSYNC();
+        for (int c = 0; c <= l; ++c) {
+            const double uc = L.uvec[c];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int r = s * WAVE + lane;
+                if (s * WAVE <= l && r <= l) p[s] = fma(As[(size_t)c * ld + r], uc, p[s]);
+            }
+        }
+        const double hinv = (h > 0.0) ? 1.0 / h2 : 0.0;
+        double kk = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int r = s * WAVE + lane;
+            p[s] = (r <= l) ? p[s] * hinv : 0.0;
+            kk += u[s] * p[s];
+        }
+        const double K = wave_sum_dpp(kk) * (0.5 * hinv);
+        double q[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int r = s * WAVE + lane;
+            q[s] = (r <= l) ? fma(-K, u[s], p[s]) : 0.0;
+            L.qvec[r] = q[s];
+        }
+        WSYNC();
+        for (int c = 0; c <= l; ++c) {
+            const double uc = L.uvec[c], qc = L.qvec[c];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int r = s * WAVE + lane;
+                if (s * WAVE <= l && r <= l) {
+                    double* pa = As + (size_t)c * ld + r;
+                    *pa = fma(-u[s], qc, fma(-q[s], uc, *pa));
+                }
+            }
+        }
+        WSYNC();
+    }
+    {
+        double a11 = 0.0, a10 = 0.0, a00 = 0.0;
+        if (lane == 1) { a11 = As[(size_t)ld + 1]; a10 = As[1]; }
+        if (lane == 0) a00 = As[0];
+        a11 = readlane_d(a11, 1); a10 = readlane_d(a10, 1); a00 = readlane_d(a00, 0);
+        if (lane == 0) { L.dd[1] = a11; L.e2[1] = a10 * a10; L.dd[0] = a00; L.e2[0] = 0.0; }
+    }
+    WSYNC();
+    const double lo = (double)(dmax + 1) * (1.0 - 1e-13) - 1e-13;
+    const double hi = (double)min(np, 2 * dmax) * (1.0 + 1e-13) + 1e-13;
+    return (double)n - sturm_largest_wave(L, np, lane, lo, hi, rounds + 1);
+}
+
+// DBSCAN + centroids for S slots per lane; labels by reference, tables in L.cx/L.cy/L.csz.
+template <int S>
+__device__ __forceinline__ void dbscan_big(const MarlEnvParams& P, int n, int lane, BigLds<S>& L, int (&label)[S],
+                                           int& n_clusters, int& ncent) {
+    const double eps2 = P.eps * P.eps;
+    uint64_t nb[S][S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = s * WAVE + lane;
+        const double xi = L.sx[i], yi = L.sy[i];
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            uint64_t word = 0;
+            const int cnt = min(WAVE, n - k * WAVE);
+            for (int b = 0; b < cnt; ++b) {
+                const double dx = xi - L.sx[k * WAVE + b], dy = yi - L.sy[k * WAVE + b];
+                const double d2 = dx * dx + dy * dy;
+                word |= (uint64_t)(d2 <= eps2) << b;
+            }
+            nb[s][k] = (i < n) ? word : 0ull;
+        }
+    }
+    uint64_t core[S], unvisited[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) cnt += __popcll(nb[s][k]);
+        core[s] = ballot64(s * WAVE + lane < n && cnt >= P.min_samples);
+        unvisited[s] = core[s];
+        label[s] = -1;
+    }
+    int num = 0;
+    while (any_words<S>(unvisited)) {
+        uint64_t comp[S], frontier[S], reached[S], hit[S];
+        bool seeded = false;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            comp[k] = 0; reached[k] = 0;
+            if (!seeded && unvisited[k]) { comp[k] = unvisited[k] & (~unvisited[k] + 1); seeded = true; }
+            frontier[k] = comp[k];
+        }
+        while (any_words<S>(frontier)) {
+            expand_big<S>(nb, frontier, hit);
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                reached[k] |= hit[k];
+                const uint64_t nw = hit[k] & core[k] & ~comp[k];
+                comp[k] |= nw;
+                frontier[k] = nw;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint64_t members = comp[s] | (reached[s] & ~core[s]);
+            if (((members >> lane) & 1ull) && label[s] == -1) label[s] = num;
+            unvisited[s] &= ~comp[s];
+        }
+        ++num;
+    }
+    bool noise_mine = false;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        L.lab[s * WAVE + lane] = label[s];
+        noise_mine = noise_mine || (s * WAVE + lane < n && label[s] == -1);
+    }
+    const bool has_noise = ballot64(noise_mine) != 0;
+    const int entries = num + (has_noise ? 1 : 0);
+    WSYNC();
+    for (int c = lane; c < entries; c += WAVE) {
+        const int id = (c < num) ? c : -1;
+        double ax = 0.0, ay = 0.0;
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) {
+            if (L.lab[i] == id) { ax = ax + L.sx[i]; ay = ay + L.sy[i]; ++cnt; }
+        }
+        L.cx[c] = ax / (double)cnt;
+        L.cy[c] = ay / (double)cnt;
+        L.csz[c] = cnt;
+    }
+    n_clusters = num;
+    ncent = entries;
+    if (num == 0) {
+        if (lane == 0) { L.cx[0] = P.arena_size / 2; L.cy[0] = P.arena_size / 2; L.csz[0] = n; }
+        ncent = 1;
+    }
+    WSYNC();
+}
+
+template <int S>
+__device__ __forceinline__ double avg_power_big(const MarlEnvParams& P, int n, int m, int lane, const BigLds<S>& L, int eband) {
+    int nm = 0;
+    for (int k = 0; k < m; ++k) nm += (L.jb[k] == eband);
+    if (nm == 0) return -80.0;
+    const double wl = kSpeedOfLight / band_hz(eband);
+    double psum = 0.0;
+    int pcnt = 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = s * WAVE + lane;
+        const double xi = L.sx[i], yi = L.sy[i];
+        for (int j = 0; j < n; ++j) {
+            double dmin = INFINITY;
+            const double mx = (xi + L.sx[j]) / 2, my = (yi + L.sy[j]) / 2;
+            for (int k = 0; k < m; ++k) {
+                if (L.jb[k] != eband) continue;
+                const double dx = L.jx[k] - mx, dy = L.jy[k] - my;
+                dmin = fmin(dmin, dx * dx + dy * dy);
+            }
+            if (i < n && j > i) {
+                const double d = fmax(sqrt(dmin), 1e-10);
+                const double g = wl / (kFourPi * d);
+                const double pw = P.P_jam_w * (g * g);
+                if (pw > 0.0) { psum += pw; ++pcnt; }
+            }
+        }
+    }
+    const double tot = wave_sum(psum);
+    const int cnt = wave_sum(pcnt);
+    if (cnt == 0) return -80.0;
+    return 10.0 * log10(tot / (double)cnt) + 30.0;
+}
+
+template <int S>
+__device__ __forceinline__ void recluster_big(const MarlEnvParams& P, const MarlEnvState& St, int e, int n, int lane,
+                                              BigLds<S>& L, int& num, int& ncent, int& pnum, int& pncent) {
+    const int KS = n + 1;
+    pnum = num; pncent = ncent;
+    for (int s = lane; s < pncent; s += WAVE) {
+        L.px[s] = St.cent_x[(size_t)e * KS + s];
+        L.py[s] = St.cent_y[(size_t)e * KS + s];
+    }
+    int label[S];
+    dbscan_big<S>(P, n, lane, L, label, num, ncent);
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+        if (s * WAVE + lane < n) St.labels[(size_t)e * n + s * WAVE + lane] = label[s];
+    for (int s = lane; s < pncent; s += WAVE) {
+        St.prev_x[(size_t)e * KS + s] = L.px[s];
+        St.prev_y[(size_t)e * KS + s] = L.py[s];
+    }
+    for (int s = lane; s < ncent; s += WAVE) {
+        St.cent_x[(size_t)e * KS + s] = L.cx[s];
+        St.cent_y[(size_t)e * KS + s] = L.cy[s];
+        St.cent_size[(size_t)e * KS + s] = L.csz[s];
+    }
+    if (lane == 0) {
+        St.prev_n_clusters[e] = pnum; St.prev_ncent[e] = pncent;
+        St.n_clusters[e] = num; St.ncent[e] = ncent;
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(WAVE) void env_step_big_kernel(MarlEnvParams P, MarlEnvState St, MarlStepIO io) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    BigLds<S>& L = *reinterpret_cast<BigLds<S>*>(smem);
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int n = P.N, m = P.M, KS = n + 1;
+    const int step = St.step_count[e] + 1;
+    const int eband = St.enemy_band[e];
+    const double arena = P.arena_size;
+    float raw_vx = 0.0f, raw_vy = 0.0f;
+    if (lane < m) {
+        const float* a = io.actions + ((size_t)e * m + lane) * 3;
+        raw_vx = a[0]; raw_vy = a[1];
+        int band = (int)a[2];
+        band = band < 0 ? 0 : (band > MARL_NUM_BANDS - 1 ? MARL_NUM_BANDS - 1 : band);
+        const float cvx = fminf(fmaxf(raw_vx, -P.v_max_f32), P.v_max_f32);
+        const float cvy = fminf(fmaxf(raw_vy, -P.v_max_f32), P.v_max_f32);
+        const float sx_ = cvx * P.dt_f32, sy_ = cvy * P.dt_f32;
+        const size_t o = (size_t)e * m + lane;
+        double x = St.jam_x[o] + (double)sx_, y = St.jam_y[o] + (double)sy_;
+        x = fmin(fmax(x, 0.0), arena);
+        y = fmin(fmax(y, 0.0), arena);
+        St.jam_x[o] = x; St.jam_y[o] = y; St.jam_band[o] = band;
+        St.last_vx[o] = raw_vx; St.last_vy[o] = raw_vy;
+        L.jx[lane] = x; L.jy[lane] = y; L.jb[lane] = band;
+        L.asg[lane] = St.assign[o];
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = s * WAVE + lane;
+        if (i < n) {
+            const size_t o = (size_t)e * n + i;
+            double nx, ny;
+            if (io.noise) { nx = io.noise[o * 2]; ny = io.noise[o * 2 + 1]; }
+            else noise_pair(io.seed, io.env_offset + e, (uint32_t)step, (uint32_t)i, P.noise_std, nx, ny);
+            double vx = St.enemy_vx[o] + nx, vy = St.enemy_vy[o] + ny;
+            double sp = sqrt(vx * vx + vy * vy);
+            sp = fmax(sp, 1e-6);
+            vx = vx / sp * P.v_enemy;
+            vy = vy / sp * P.v_enemy;
+            double x = St.enemy_x[o] + vx * P.dt, y = St.enemy_y[o] + vy * P.dt;
+            if (x < 0.0) { x = -x; vx = -vx; }
+            if (x > arena) { x = 2 * arena - x; vx = -vx; }
+            if (y < 0.0) { y = -y; vy = -vy; }
+            if (y > arena) { y = 2 * arena - y; vy = -vy; }
+            x = fmin(fmax(x, 0.0), arena);
+            y = fmin(fmax(y, 0.0), arena);
+            St.enemy_x[o] = x; St.enemy_y[o] = y; St.enemy_vx[o] = vx; St.enemy_vy[o] = vy;
+            L.sx[i] = x; L.sy[i] = y;
+        }
+    }
+    int num = St.n_clusters[e], ncent = St.ncent[e];
+    WSYNC();
+    if (step % P.K_recompute == 0) {
+        int pnum, pncent;
+        recluster_big<S>(P, St, e, n, lane, L, num, ncent, pnum, pncent);
+        if (should_reassign_wave(P, lane, L, num, ncent, pnum, pncent)) {
+            assign_proportional_wave(m, lane, L, num, ncent);
+            if (lane < m) St.assign[(size_t)e * m + lane] = L.asg[lane];
+        }
+    } else {
+        for (int s = lane; s < ncent; s += WAVE) {
+            L.cx[s] = St.cent_x[(size_t)e * KS + s];
+            L.cy[s] = St.cent_y[(size_t)e * KS + s];
+            L.csz[s] = St.cent_size[(size_t)e * KS + s];
+        }
+        WSYNC();
+    }
+    uint64_t adj[S][S], jam[S][S];
+    pair_rows_big<S, false>(adj, L, n, m, lane, eband, P.comm_d2_max[eband]);
+    pair_rows_big<S, true>(jam, L, n, m, lane, eband, P.jam_d2_max[eband]);
+    store_bits_big<S>(io.adj_bits, e, n, lane, adj);
+    store_bits_big<S>(io.jam_bits, e, n, lane, jam);
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int k = 0; k < S; ++k) adj[s][k] &= ~jam[s][k];
+    const int ld = big_ld(n);
+    const double lam = lambda2_big<S>(adj, n, lane, L, P.lambda2_rounds, St.workspace + (size_t)e * ld * ld);
+    const double lam0 = St.lambda2_initial[e];
+    const RewardOut rw = reward_obs_wave(P, n, m, lane, L, eband, num, ncent, lam, lam0, raw_vx, raw_vy);
+    if (lane < m) {
+        float* o = io.obs + ((size_t)e * m + lane) * MARL_OBS_DIM;
+        o[0] = rw.o0; o[1] = rw.o1; o[2] = rw.o2; o[3] = rw.o3; o[4] = rw.o4;
+    }
+    if (io.reward_terms && lane == 0) {
+        float* r = io.reward_terms + (size_t)e * 5;
+        r[0] = rw.r0; r[1] = rw.r1; r[2] = rw.r2; r[3] = rw.r3; r[4] = rw.r4;
+    }
+    double avgp = 0.0;
+    if (io.avg_power_dbm) avgp = avg_power_big<S>(P, n, m, lane, L, eband);
+    if (lane == 0) {
+        St.step_count[e] = step;
+        io.reward[e] = (float)rw.total;
+        io.truncated[e] = (uint8_t)(step >= P.max_steps);
+        if (io.lambda2) io.lambda2[e] = lam;
+        if (io.avg_power_dbm) io.avg_power_dbm[e] = avgp;
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(WAVE) void env_reset_big_kernel(MarlEnvParams P, MarlEnvState St, MarlResetIO io) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    BigLds<S>& L = *reinterpret_cast<BigLds<S>*>(smem);
+    const int e = blockIdx.x, lane = threadIdx.x;
+    if (io.mask && io.mask[e] == 0) return;
+    const int n = P.N, m = P.M;
+    const double arena = P.arena_size;
+    const uint64_t genv = io.env_offset + e;
+    const uint32_t k0 = (uint32_t)io.seed, k1 = (uint32_t)(io.seed >> 32);
+    int num = St.n_clusters[e], ncent = St.ncent[e];
+    int eband = 2;
+    double lam0 = 0.0;
+    const bool host_init = io.enemy_pos != nullptr;
+    const int attempts = host_init ? 1 : (P.max_reset_attempts > 0 ? P.max_reset_attempts : 1);
+    const int ld = big_ld(n);
+    for (int attempt = 0; attempt < attempts; ++attempt) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int i = s * WAVE + lane;
+            if (i < n) {
+                const size_t o = (size_t)e * n + i;
+                double x, y, vx, vy;
+                if (host_init) {
+                    x = io.enemy_pos[o * 2]; y = io.enemy_pos[o * 2 + 1];
+                    vx = io.enemy_vel[o * 2]; vy = io.enemy_vel[o * 2 + 1];
+                } else {
+                    uint32_t r[4], r2[4];
+                    philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)i << 8) ^ STREAM_RESET_ENEMY,
+                               (uint32_t)io.episode, (uint32_t)attempt, k0, k1, r);
+                    philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)i << 8) ^ STREAM_RESET_ENEMY,
+                               (uint32_t)io.episode, (uint32_t)attempt | 0x80000000u, k0, k1, r2);
+                    const double margin = arena * 0.1;
+                    x = margin + (arena - margin - margin) * u01(r[0], r[1]);
+                    y = margin + (arena - margin - margin) * u01(r[2], r[3]);
+                    double sn, cs;
+                    sincos(kTwoPi * u01(r2[0], r2[1]), &sn, &cs);
+                    vx = P.v_enemy * cs; vy = P.v_enemy * sn;
+                }
+                St.enemy_x[o] = x; St.enemy_y[o] = y; St.enemy_vx[o] = vx; St.enemy_vy[o] = vy;
+                L.sx[i] = x; L.sy[i] = y;
+            }
+        }
+        if (io.enemy_band) {
+            eband = io.enemy_band[e];
+        } else {
+            uint32_t r[4];
+            philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ STREAM_RESET_ENV, (uint32_t)io.episode,
+                       (uint32_t)attempt, k0, k1, r);
+            eband = (int)(r[0] & 3u);
+        }
+        eband = eband < 0 ? 0 : (eband > 3 ? 3 : eband);
+        WSYNC();
+        int pnum, pncent;
+        recluster_big<S>(P, St, e, n, lane, L, num, ncent, pnum, pncent);
+        WSYNC();
+        uint64_t adj[S][S];
+        pair_rows_big<S, false>(adj, L, n, m, lane, eband, P.comm_d2_max[eband]);
+        lam0 = lambda2_big<S>(adj, n, lane, L, P.lambda2_rounds, St.workspace + (size_t)e * ld * ld);
+        if (lam0 >= P.min_lambda2_initial) break;
+    }
+    if (lane < m) L.asg[lane] = MARL_ASSIGN_NONE;
+    WSYNC();
+    if (!P.random_jammer_start) assign_proportional_wave(m, lane, L, num, ncent);
+    if (lane < m) {
+        const size_t o = (size_t)e * m + lane;
+        double ix, iy;
+        int band;
+        uint32_t r[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0};
+        if (io.jam_init == nullptr || io.jam_band == nullptr) {
+            philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)lane << 8) ^ STREAM_RESET_JAMMER,
+                       (uint32_t)io.episode, 0u, k0, k1, r);
+            philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)lane << 8) ^ STREAM_RESET_JAMMER,
+                       (uint32_t)io.episode, 1u, k0, k1, r2);
+        }
+        if (io.jam_init) { ix = io.jam_init[o * 2]; iy = io.jam_init[o * 2 + 1]; }
+        else if (P.random_jammer_start) {
+            ix = 0.1 * arena + (0.9 * arena - 0.1 * arena) * u01(r[0], r[1]);
+            iy = 0.1 * arena + (0.9 * arena - 0.1 * arena) * u01(r[2], r[3]);
+        } else {
+            ix = -P.spread + (P.spread + P.spread) * u01(r[0], r[1]);
+            iy = -P.spread + (P.spread + P.spread) * u01(r[2], r[3]);
+        }
+        band = io.jam_band ? io.jam_band[o] : (int)(r2[0] & 3u);
+        double x = ix, y = iy;
+        if (!P.random_jammer_start) {
+            const int c = L.asg[lane];
+            x = 0.0; y = 0.0;
+            int slot = -1;
+            if (c >= 0 && c < num) slot = c;
+            else if (c == -1 && ncent > num) slot = num;
+            if (slot >= 0) {
+                x = fmin(fmax(L.cx[slot] + ix, 0.0), arena);
+                y = fmin(fmax(L.cy[slot] + iy, 0.0), arena);
+            }
+        }
+        St.jam_x[o] = x; St.jam_y[o] = y; St.jam_band[o] = band;
+        St.last_vx[o] = 0.0f; St.last_vy[o] = 0.0f;
+        St.assign[o] = L.asg[lane];
+        L.jx[lane] = x; L.jy[lane] = y; L.jb[lane] = band;
+    }
+    WSYNC();
+    const RewardOut rw = reward_obs_wave(P, n, m, lane, L, eband, num, ncent, lam0, lam0, 0.0f, 0.0f);
+    if (lane < m && io.obs) {
+        float* o = io.obs + ((size_t)e * m + lane) * MARL_OBS_DIM;
+        o[0] = rw.o0; o[1] = rw.o1; o[2] = rw.o2; o[3] = rw.o3; o[4] = rw.o4;
+    }
+    if (lane == 0) {
+        St.step_count[e] = 0;
+        St.enemy_band[e] = eband;
+        St.lambda2_initial[e] = lam0;
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(WAVE) void pair_bits_big_kernel(MarlEnvParams P, const double* x, const double* y,
+                                                             const int32_t* band, const double* jx, const double* jy,
+                                                             const int32_t* jb, uint32_t* bits, int jam) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    BigLds<S>& L = *reinterpret_cast<BigLds<S>*>(smem);
+    const int e = blockIdx.x, lane = threadIdx.x, n = P.N, m = P.M;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = s * WAVE + lane;
+        if (i < n) { L.sx[i] = x[(size_t)e * n + i]; L.sy[i] = y[(size_t)e * n + i]; }
+    }
+    if (jam && lane < m) {
+        L.jx[lane] = jx[(size_t)e * m + lane]; L.jy[lane] = jy[(size_t)e * m + lane];
+        L.jb[lane] = jb[(size_t)e * m + lane];
+    }
+    WSYNC();
+    int b = band[e]; b = b < 0 ? 0 : (b > 3 ? 3 : b);
+    uint64_t rows[S][S];
+    if (jam) pair_rows_big<S, true>(rows, L, n, m, lane, b, P.jam_d2_max[b]);
+    else pair_rows_big<S, false>(rows, L, n, m, lane, b, P.comm_d2_max[b]);
+    store_bits_big<S>(bits, e, n, lane, rows);
+}
+
+template <int S>
+__global__ __launch_bounds__(WAVE) void lambda2_bits_big_kernel(int n, const uint32_t* bits, double* lambda2, int rounds,
+                                                                double* ws) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    BigLds<S>& L = *reinterpret_cast<BigLds<S>*>(smem);
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int W = (n + 31) / 32;
+    uint64_t rows[S][S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = s * WAVE + lane;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            uint64_t w = 0;
+            if (i < n) {
+                const uint32_t* p = bits + ((size_t)e * n + i) * W;
+                if (2 * k < W) w = p[2 * k];
+                if (2 * k + 1 < W) w |= (uint64_t)p[2 * k + 1] << 32;
+                w &= word_mask<S>(n, k);
+                if (k == s) w &= ~(1ull << lane);
+            }
+            rows[s][k] = w;
+        }
+    }
+    const int ld = big_ld(n);
+    const double lam = lambda2_big<S>(rows, n, lane, L, rounds, ws + (size_t)e * ld * ld);
+    if (lane == 0) lambda2[e] = lam;
+}
+
+template <int S>
+__global__ __launch_bounds__(WAVE) void dbscan_big_kernel(MarlEnvParams P, const double* x, const double* y,
+                                                          int32_t* labels, double* cx, double* cy, int32_t* csz,
+                                                          int32_t* n_clusters, int32_t* ncent_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    BigLds<S>& L = *reinterpret_cast<BigLds<S>*>(smem);
+    const int e = blockIdx.x, lane = threadIdx.x, n = P.N, KS = n + 1;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = s * WAVE + lane;
+        if (i < n) { L.sx[i] = x[(size_t)e * n + i]; L.sy[i] = y[(size_t)e * n + i]; }
+    }
+    WSYNC();
+    int num, ncent, label[S];
+    dbscan_big<S>(P, n, lane, L, label, num, ncent);
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+        if (s * WAVE + lane < n) labels[(size_t)e * n + s * WAVE + lane] = label[s];
+    for (int s = lane; s < ncent; s += WAVE) {
+        cx[(size_t)e * KS + s] = L.cx[s];
+        cy[(size_t)e * KS + s] = L.cy[s];
+        csz[(size_t)e * KS + s] = L.csz[s];
+    }
+    if (lane == 0) { n_clusters[e] = num; ncent_out[e] = ncent; }
+}
+
 // ------------------------------------------------------------------ host side
 int hip_check(hipError_t err) {
     if (err == hipSuccess) return MARL_OK;
@@ -988,6 +1736,20 @@ int check_sizes(const MarlEnvParams* p) {
 }
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// Global scratch of the lambda2 solver for N > 64: one ld x ld float64 matrix per env.
+size_t workspace_bytes(int N, int E) {
+    if (N <= WAVE) return 0;
+    const size_t ld = (size_t)big_ld(N);
+    return (size_t)E * ld * ld * sizeof(double);
+}
+
+#define MARL_DISPATCH_SLOTS(N, kern, grid, stream, ...)                                                            \
+    switch (((N) + WAVE - 1) / WAVE) {                                                                             \
+        case 2: hipLaunchKernelGGL((kern<2>), grid, dim3(WAVE), sizeof(BigLds<2>), (hipStream_t)(stream), __VA_ARGS__); break; \
+        case 3: hipLaunchKernelGGL((kern<3>), grid, dim3(WAVE), sizeof(BigLds<3>), (hipStream_t)(stream), __VA_ARGS__); break; \
+        default: hipLaunchKernelGGL((kern<4>), grid, dim3(WAVE), sizeof(BigLds<4>), (hipStream_t)(stream), __VA_ARGS__); break; \
+    }
 
 // The wave kernels are instantiated per register-matrix width NPAD = N rounded up to 8.
 #define MARL_LAUNCH_NPAD(NP, kern, grid, lds, stream, ...) \
@@ -1058,6 +1820,7 @@ size_t marl_state_bytes(const MarlEnvParams* p, int32_t E) {
     b += 2 * align256(e * ks * 8);       // prev x, y
     b += 2 * align256(e * 4);            // prev_n_clusters, prev_ncent
     b += align256(e * m * 4);            // assign
+    b += align256(workspace_bytes(p->N, E)); // lambda2 matrix workspace (N > 64 only)
     return b;
 }
 
@@ -1084,6 +1847,8 @@ int marl_state_bind(MarlEnvState* s, const MarlEnvParams* p, int32_t E, void* ba
     s->prev_x = (double*)take(e * ks * 8); s->prev_y = (double*)take(e * ks * 8);
     s->prev_n_clusters = (int32_t*)take(e * 4); s->prev_ncent = (int32_t*)take(e * 4);
     s->assign = (int32_t*)take(e * m * 4);
+    const size_t wsb = workspace_bytes(p->N, E);
+    s->workspace = wsb ? (double*)take(wsb) : nullptr;
     return MARL_OK;
 }
 
@@ -1094,7 +1859,11 @@ int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepI
     if (s->E < 1 || io->actions == nullptr || io->obs == nullptr || io->reward == nullptr ||
         io->truncated == nullptr || s->enemy_x == nullptr)
         return MARL_EINVAL;
-    if (p->N > WAVE) return MARL_EUNSUPPORTED;
+    if (p->N > WAVE) {
+        if (s->workspace == nullptr) return MARL_EINVAL;
+        MARL_DISPATCH_SLOTS(p->N, env_step_big_kernel, dim3(s->E), stream, *p, *s, *io);
+        return hip_check(hipGetLastError());
+    }
     MARL_DISPATCH_NPAD(p->N, env_step_wave_kernel, dim3(s->E), wave_lds_bytes(p->N), stream, *p, *s, *io);
     return hip_check(hipGetLastError());
 }
@@ -1105,7 +1874,11 @@ int marl_env_reset(const MarlEnvParams* p, const MarlEnvState* s, const MarlRese
     if (rc != MARL_OK) return rc;
     if (s->E < 1 || s->enemy_x == nullptr) return MARL_EINVAL;
     if ((io->enemy_pos == nullptr) != (io->enemy_vel == nullptr)) return MARL_EINVAL;
-    if (p->N > WAVE) return MARL_EUNSUPPORTED;
+    if (p->N > WAVE) {
+        if (s->workspace == nullptr) return MARL_EINVAL;
+        MARL_DISPATCH_SLOTS(p->N, env_reset_big_kernel, dim3(s->E), stream, *p, *s, *io);
+        return hip_check(hipGetLastError());
+    }
     MARL_DISPATCH_NPAD(p->N, env_reset_wave_kernel, dim3(s->E), wave_lds_bytes(p->N), stream, *p, *s, *io);
     return hip_check(hipGetLastError());
 }
@@ -1115,7 +1888,11 @@ int marl_adjacency_bits(const MarlEnvParams* p, int32_t E, const double* x, cons
     int rc = check_sizes(p);
     if (rc != MARL_OK) return rc;
     if (E < 1 || !x || !y || !band || !bits) return MARL_EINVAL;
-    if (p->N > WAVE) return MARL_EUNSUPPORTED;
+    if (p->N > WAVE) {
+        MARL_DISPATCH_SLOTS(p->N, pair_bits_big_kernel, dim3(E), stream, *p, x, y, band, (const double*)nullptr,
+                            (const double*)nullptr, (const int32_t*)nullptr, bits, 0);
+        return hip_check(hipGetLastError());
+    }
     hipLaunchKernelGGL(adjacency_bits_kernel, dim3(E), dim3(WAVE), wave_lds_bytes(p->N), (hipStream_t)stream, *p, x, y,
                        band, bits);
     return hip_check(hipGetLastError());
@@ -1127,17 +1904,31 @@ int marl_jam_mask_bits(const MarlEnvParams* p, int32_t E, const double* x, const
     int rc = check_sizes(p);
     if (rc != MARL_OK) return rc;
     if (E < 1 || !x || !y || !band || !jam_x || !jam_y || !jam_band || !bits) return MARL_EINVAL;
-    if (p->N > WAVE) return MARL_EUNSUPPORTED;
+    if (p->N > WAVE) {
+        MARL_DISPATCH_SLOTS(p->N, pair_bits_big_kernel, dim3(E), stream, *p, x, y, band, jam_x, jam_y, jam_band, bits, 1);
+        return hip_check(hipGetLastError());
+    }
     hipLaunchKernelGGL(jam_bits_kernel, dim3(E), dim3(WAVE), wave_lds_bytes(p->N), (hipStream_t)stream, *p, x, y, band,
                        jam_x, jam_y, jam_band, bits);
     return hip_check(hipGetLastError());
 }
 
+size_t marl_lambda2_workspace_bytes(int32_t N, int32_t E) {
+    if (N < 1 || N > MARL_MAX_N || E < 1) return 0;
+    return workspace_bytes(N, E);
+}
+
 int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t* bits, double* lambda2, int32_t rounds,
-                           void* stream) {
+                           void* workspace, void* stream) {
     if (N < 1 || E < 1 || !bits || !lambda2) return MARL_EINVAL;
-    if (N > WAVE) return MARL_EUNSUPPORTED;
+    if (N > MARL_MAX_N) return MARL_EUNSUPPORTED;
     if (rounds <= 0) rounds = 8;
+    if (N > WAVE) {
+        if (workspace == nullptr) return MARL_EINVAL;
+        MARL_DISPATCH_SLOTS(N, lambda2_bits_big_kernel, dim3(E), stream, (int)N, bits, lambda2, (int)rounds,
+                            (double*)workspace);
+        return hip_check(hipGetLastError());
+    }
     MARL_DISPATCH_NPAD(N, lambda2_bits_kernel, dim3(E), wave_lds_bytes(N), stream, (int)N, bits, lambda2, (int)rounds);
     return hip_check(hipGetLastError());
 }
@@ -1149,7 +1940,11 @@ int marl_dbscan(const MarlEnvParams* p, int32_t E, const double* x, const double
     if (rc != MARL_OK) return rc;
     if (E < 1 || !x || !y || !labels || !cent_x || !cent_y || !cent_size || !n_clusters || !ncent)
         return MARL_EINVAL;
-    if (p->N > WAVE) return MARL_EUNSUPPORTED;
+    if (p->N > WAVE) {
+        MARL_DISPATCH_SLOTS(p->N, dbscan_big_kernel, dim3(E), stream, *p, x, y, labels, cent_x, cent_y, cent_size,
+                            n_clusters, ncent);
+        return hip_check(hipGetLastError());
+    }
     hipLaunchKernelGGL(dbscan_kernel, dim3(E), dim3(WAVE), wave_lds_bytes(p->N), (hipStream_t)stream, *p, x, y, labels,
                        cent_x, cent_y, cent_size, n_clusters, ncent);
     return hip_check(hipGetLastError());

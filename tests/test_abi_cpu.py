@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header_layout():
     # 8 int32 + 19 double + 12 double + 4 float
     assert C.sizeof(_lib.MarlEnvParams) == 8 * 4 + 31 * 8 + 4 * 4
-    assert C.sizeof(_lib.MarlEnvState) == 8 + 23 * 8
+    assert C.sizeof(_lib.MarlEnvState) == 8 + 24 * 8
     assert C.sizeof(_lib.MarlStepIO) == 12 * 8
     assert C.sizeof(_lib.MarlResetIO) == 10 * 8
 
@@ -76,9 +76,16 @@ def test_state_carving_is_disjoint_and_aligned():
     st = _lib.MarlEnvState()
     base = 0x10000000
     _lib.check(lib.marl_state_bind(C.byref(st), C.byref(p), E, C.c_void_p(base)))
-    ptrs = sorted(getattr(st, n) for n in _lib._STATE_ARRAYS)
+    assert st.workspace is None                       # N <= 64 needs no lambda2 scratch
+    ptrs = sorted(getattr(st, n) for n in _lib._STATE_ARRAYS if n != "workspace")
     assert ptrs[0] == base and all(q % 256 == 0 for q in ptrs)
     assert len(set(ptrs)) == len(ptrs) and ptrs[-1] < base + nbytes
+    # N = 200: one 200 x 200 float64 matrix per env on top
+    p2 = EnvConfig.fast_preset(N=200, M=16).to_params()
+    n2 = lib.marl_state_bytes(C.byref(p2), E)
+    assert lib.marl_lambda2_workspace_bytes(200, E) == E * 200 * 200 * 8 and n2 > E * 200 * 200 * 8
+    _lib.check(lib.marl_state_bind(C.byref(st), C.byref(p2), E, C.c_void_p(base)))
+    assert st.workspace is not None and st.workspace + E * 200 * 200 * 8 <= base + n2
     assert lib.marl_state_bind(C.byref(st), C.byref(p), E, C.c_void_p(base + 8)) == _lib.MARL_EINVAL
 
 
@@ -92,7 +99,7 @@ def test_argument_validation_without_launch():
     io = _lib.MarlStepIO()
     assert lib.marl_env_step(C.byref(p), C.byref(st), C.byref(io), None) == _lib.MARL_EINVAL
     assert lib.marl_env_step(None, None, None, None) == _lib.MARL_EINVAL
-    assert lib.marl_lambda2_from_bits(0, 1, None, None, 0, None) == _lib.MARL_EINVAL
+    assert lib.marl_lambda2_from_bits(0, 1, None, None, 0, None, None) == _lib.MARL_EINVAL
     assert lib.marl_gae(0, 1, None, None, None, None, None, 0.99, 0.95, None, None, None) == _lib.MARL_EINVAL
     assert b"invalid" in lib.marl_strerror(_lib.MARL_EINVAL)
 

@@ -18,7 +18,7 @@ from oracle import jammer_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-MAXN = 64   # sizes the wave-per-env kernels cover
+MAXN = 256   # N <= 64: one enemy per lane; 65..256: up to four per lane
 
 
 def cfg_from(p: orc.EnvParams, **kw) -> EnvConfig:
@@ -45,6 +45,18 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def lambda2_bits(n, E, bits, rounds=0):
+    """marl_lambda2_from_bits with its scratch buffer (needed for N > 64 only)."""
+    lib = _lib.load()
+    out = torch.zeros(E, dtype=torch.float64, device="cuda")
+    nb = lib.marl_lambda2_workspace_bytes(n, E)
+    ws = torch.zeros(max(nb, 8), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.marl_lambda2_from_bits(n, E, bits.data_ptr(), out.data_ptr(), rounds,
+                                          ws.data_ptr() if nb else None, stream()))
+    torch.cuda.synchronize()
+    return out
+
+
 # ---------------------------------------------------------------- stage ops vs reference vectors
 def _stage_groups():
     groups = {}
@@ -58,8 +70,6 @@ def _stage_groups():
 @pytest.mark.parametrize("gi", range(len(_stage_groups())))
 def test_stage_ops_match_reference_vectors(gi):
     p, cases = _stage_groups()[gi]
-    if p.N > MAXN:
-        pytest.skip("N > 64 runs on the workgroup-per-env kernels")
     lib = _lib.load()
     P = cfg_from(p).to_params()
     E, N, M = len(cases), p.N, p.M
@@ -77,10 +87,8 @@ def test_stage_ops_match_reference_vectors(gi):
     _lib.check(lib.marl_jam_mask_bits(C.byref(P), E, x.data_ptr(), y.data_ptr(), band.data_ptr(), jx.data_ptr(),
                                       jy.data_ptr(), jb.data_ptr(), jam.data_ptr(), stream()))
     eff = adj & ~jam
-    lam = torch.zeros(E, dtype=torch.float64, device="cuda")
-    lam0 = torch.zeros(E, dtype=torch.float64, device="cuda")
-    _lib.check(lib.marl_lambda2_from_bits(N, E, eff.data_ptr(), lam.data_ptr(), 0, stream()))
-    _lib.check(lib.marl_lambda2_from_bits(N, E, adj.data_ptr(), lam0.data_ptr(), 0, stream()))
+    lam = lambda2_bits(N, E, eff.contiguous())
+    lam0 = lambda2_bits(N, E, adj)
     labels = torch.zeros(E, N, dtype=torch.int32, device="cuda")
     cx = torch.zeros(E, N + 1, dtype=torch.float64, device="cuda")
     cy = torch.zeros(E, N + 1, dtype=torch.float64, device="cuda")
@@ -129,9 +137,7 @@ def test_lambda2_closed_forms_and_random_graphs():
     for A, want in todo:
         n = A.shape[0]
         bits = dev(orc.pack_rows(A).view(np.int32)[None], torch.int32)
-        out = torch.zeros(1, dtype=torch.float64, device="cuda")
-        _lib.check(lib.marl_lambda2_from_bits(n, 1, bits.data_ptr(), out.data_ptr(), 0, stream()))
-        got = float(out[0])
+        got = float(lambda2_bits(n, 1, bits)[0])
         assert abs(got - want) <= 1e-6 * max(1.0, abs(want)), (n, got, want)
 
 
@@ -147,9 +153,7 @@ def test_lambda2_accuracy_with_more_rounds():
         mats.append(orc.pack_rows(A).view(np.int32))
         want.append(orc.lambda2_of_laplacian(orc.laplacian(A)))
     bits = dev(np.stack(mats), torch.int32)
-    out = torch.zeros(E, dtype=torch.float64, device="cuda")
-    _lib.check(lib.marl_lambda2_from_bits(n, E, bits.data_ptr(), out.data_ptr(), 9, stream()))
-    got = out.cpu().numpy()
+    got = lambda2_bits(n, E, bits, rounds=9).cpu().numpy()
     assert np.max(np.abs(got - np.array(want))) < 1e-9
 
 
@@ -237,8 +241,6 @@ def test_gae_matches_reference_buffer():
 def test_trajectory_matches_reference(name):
     z = gu.load(f"traj_{name}.npz")
     p = gu.traj_params(z)
-    if p.N > MAXN:
-        pytest.skip("N > 64 runs on the workgroup-per-env kernels")
     resets = gu.traj_resets(z)
     E = 3      # the same trajectory in every env of a small batch
     env = BatchedJammerEnv(E, cfg_from(p), auto_reset=False, track_avg_power=True, debug_bits=True)
@@ -296,7 +298,8 @@ def test_trajectory_matches_reference(name):
 
 
 # ---------------------------------------------------------------- batched run vs the oracle on seeded inputs
-@pytest.mark.parametrize("N,M,E,steps", [(10, 4, 48, 25), (50, 8, 24, 21), (64, 16, 6, 11), (3, 1, 8, 12)])
+@pytest.mark.parametrize("N,M,E,steps", [(10, 4, 48, 25), (50, 8, 24, 21), (64, 16, 6, 11), (3, 1, 8, 12),
+                                         (65, 8, 4, 11), (130, 16, 3, 11), (200, 16, 3, 6), (256, 64, 2, 5)])
 def test_batched_steps_match_oracle(N, M, E, steps):
     rng = np.random.RandomState(100 + N)
     p = orc.EnvParams.fast_preset(N=N, M=M)

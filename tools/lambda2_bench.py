@@ -32,11 +32,11 @@ def run(N, npv, rounds, p_missing=0.3):
     bits = torch.from_numpy(np.stack(base)).cuda().repeat(E // 64, 1, 1).contiguous()
     out = torch.zeros(E, dtype=torch.float64, device="cuda")
     for _ in range(3):
-        lib.marl_lambda2_from_bits(N, E, bits.data_ptr(), out.data_ptr(), rounds, st())
+        lib.marl_lambda2_from_bits(N, E, bits.data_ptr(), out.data_ptr(), rounds, None, st())
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(10):
-        lib.marl_lambda2_from_bits(N, E, bits.data_ptr(), out.data_ptr(), rounds, st())
+        lib.marl_lambda2_from_bits(N, E, bits.data_ptr(), out.data_ptr(), rounds, None, st())
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / 10 * 1e3
 

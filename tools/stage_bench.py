@@ -39,9 +39,9 @@ def timeit(name, fn, reps=20):
     print(f"{name:28s} {ms*1e3:9.1f} us/launch  {ms*1e6/E:8.1f} ns/env")
 
 
-timeit("lambda2_from_bits", lambda: lib.marl_lambda2_from_bits(N, E, eff.data_ptr(), out.data_ptr(), 0, st()))
+timeit("lambda2_from_bits", lambda: lib.marl_lambda2_from_bits(N, E, eff.data_ptr(), out.data_ptr(), 0, None, st()))
 full = env.adj_bits.contiguous()
-timeit("lambda2 (complete graphs)", lambda: lib.marl_lambda2_from_bits(N, E, full.data_ptr(), out.data_ptr(), 0, st()))
+timeit("lambda2 (complete graphs)", lambda: lib.marl_lambda2_from_bits(N, E, full.data_ptr(), out.data_ptr(), 0, None, st()))
 timeit("adjacency_bits", lambda: lib.marl_adjacency_bits(C.byref(P), E, v["enemy_x"].data_ptr(), v["enemy_y"].data_ptr(),
                                                          v["enemy_band"].data_ptr(), bits.data_ptr(), st()))
 timeit("jam_mask_bits", lambda: lib.marl_jam_mask_bits(C.byref(P), E, v["enemy_x"].data_ptr(), v["enemy_y"].data_ptr(),
