@@ -109,9 +109,8 @@ __device__ __forceinline__ void noise_pair(uint64_t seed, uint64_t genv, uint32_
 struct WaveLds {
     double sx[WAVE], sy[WAVE];        // enemy positions
     double jx[WAVE], jy[WAVE];        // jammer positions
-    double2 uq[WAVE];                 // Householder vectors (u_c, q_c) interleaved for one 16-byte broadcast read
-    double dd[WAVE], e2[WAVE];        // tridiagonal: diagonal, squared off-diagonal
-    __attribute__((aligned(16))) double urow[WAVE];   // pivot row of the current Householder step
+    __attribute__((aligned(16))) double uvec[WAVE], qvec[WAVE];   // Householder vectors u, q
+    double2 de[WAVE];                 // tridiagonal: (diagonal, squared off-diagonal) per row
     unsigned long long xfer[WAVE];    // lane-to-lane hand-over of 64-bit rows
     double cx[WAVE + 2], cy[WAVE + 2];  // centroids in dict order
     double px[WAVE + 2], py[WAVE + 2];  // previous centroids
@@ -179,6 +178,25 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 
+// 1/x and sqrt(x) (x > 0) from the hardware seeds (v_rcp_f64 / v_rsq_f64, about 23 good bits)
+// and two Newton / Goldschmidt steps: accurate to an ulp or two, a third of the instructions of
+// the correctly rounded library versions.  Used only inside the eigensolver, where an ulp is noise.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fast_sqrt(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    double s = x * r, hh = 0.5 * r;
+    double e = fma(-hh, s, 0.5);
+    s = fma(s, e, s);
+    hh = fma(hh, e, hh);
+    e = fma(-hh, s, 0.5);
+    return fma(s, e, s);
+}
+
 // Column loops of the register-resident Householder step.  Row j of the matrix lives in
 // the registers a[0..NPAD) of lane j, so every index must be a constant already when the
 // code is parsed (a loop variable, even of a fully unrollable loop, makes the compiler
@@ -195,73 +213,61 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 template <int NPAD, int B>
 struct ColBlocks {
-    // p += A[:, 8B..8B+7] * u[8B..8B+7]; u_c comes from lane c through SGPRs
-    static __device__ __forceinline__ void matvec(const double (&a)[NPAD], double uj, int l, double& p0, double& p1) {
+    // p += A[:, 8B..8B+7] * u[8B..8B+7]; (u_c, u_c+1) by one 16-byte broadcast LDS read
+    static __device__ __forceinline__ void matvec(const double (&a)[NPAD], const double* uvec, int l, double& p0, double& p1) {
         if constexpr (B * 8 < NPAD) {
             if (B * 8 > l) return;
             static_for<0, 4>([&](auto k) {
                 constexpr int c = B * 8 + 2 * decltype(k)::value;
-                p0 = fma(a[c], readlane_d(uj, c), p0);
-                p1 = fma(a[c + 1], readlane_d(uj, c + 1), p1);
+                const double2 t = *reinterpret_cast<const double2*>(uvec + c);
+                p0 = fma(a[c], t.x, p0);
+                p1 = fma(a[c + 1], t.y, p1);
             });
-            asm volatile("" : "+v"(p0), "+v"(p1));
-            ColBlocks<NPAD, B + 1>::matvec(a, uj, l, p0, p1);
+            // pin the partial sums here (see update): keeps this block's loads behind its exit test
+            asm volatile("" : "+v"(p0), "+v"(p1) :: "memory");
+            ColBlocks<NPAD, B + 1>::matvec(a, uvec, l, p0, p1);
         }
     }
-    // A[:, c] -= u q_c + q u_c; (u_c, q_c) by one 16-byte broadcast LDS read per column.
-    // Lane l (the next pivot) also copies its updated row to urow for the next step.
-    static __device__ __forceinline__ void update(double (&a)[NPAD], double uj, double qj, int lane, int l,
-                                                  const double2* uq, double* urow) {
+    // A[:, c] -= u q_c + q u_c with (u_c, u_c+1) and (q_c, q_c+1) by 16-byte broadcast LDS reads.
+    static __device__ __forceinline__ void update(double (&a)[NPAD], double uj, double qj, int l,
+                                                  const double* uvec, const double* qvec) {
         if constexpr (B * 8 < NPAD) {
             if (B * 8 > l) return;
-            static_for<0, 8>([&](auto k) {
-                constexpr int c = B * 8 + decltype(k)::value;
-                const double2 t = uq[c];
-                a[c] = fma(-uj, t.y, fma(-qj, t.x, a[c]));
+            static_for<0, 4>([&](auto k) {
+                constexpr int c = B * 8 + 2 * decltype(k)::value;
+                const double2 tu = *reinterpret_cast<const double2*>(uvec + c);
+                const double2 tq = *reinterpret_cast<const double2*>(qvec + c);
+                a[c] = fma(-uj, tq.x, fma(-qj, tu.x, a[c]));
+                a[c + 1] = fma(-uj, tq.y, fma(-qj, tu.y, a[c + 1]));
             });
-            if (lane == l) {
-                static_for<0, 4>([&](auto k) {
-                    constexpr int c = B * 8 + 2 * decltype(k)::value;
-                    *reinterpret_cast<double2*>(urow + c) = make_double2(a[c], a[c + 1]);
-                });
-            }
             // pin this block's results here: without it the compiler issues every block's loads
             // first and sinks all the arithmetic behind them, which needs 4 registers per column
             asm volatile("" : "+v"(a[B * 8]), "+v"(a[B * 8 + 1]), "+v"(a[B * 8 + 2]), "+v"(a[B * 8 + 3]),
                               "+v"(a[B * 8 + 4]), "+v"(a[B * 8 + 5]), "+v"(a[B * 8 + 6]), "+v"(a[B * 8 + 7])
                          :: "memory");
-            ColBlocks<NPAD, B + 1>::update(a, uj, qj, lane, l, uq, urow);
-        }
-    }
-    // lane `src` writes columns 0..l (rounded up to the block) of its row to urow
-    static __device__ __forceinline__ void dump_row(const double (&a)[NPAD], int lane, int src, int l, double* urow) {
-        if constexpr (B * 8 < NPAD) {
-            if (B * 8 > l) return;
-            if (lane == src) {
-                static_for<0, 4>([&](auto k) {
-                    constexpr int c = B * 8 + 2 * decltype(k)::value;
-                    *reinterpret_cast<double2*>(urow + c) = make_double2(a[c], a[c + 1]);
-                });
-            }
-            ColBlocks<NPAD, B + 1>::dump_row(a, lane, src, l, urow);
+            ColBlocks<NPAD, B + 1>::update(a, uj, qj, l, uvec, qvec);
         }
     }
 };
 
-// Second-smallest eigenvalue of L = D - A for the graph whose adjacency rows are
-// `row` (communication_graph.py:184-286; the reference calls LAPACK dsyevr through
-// scipy.linalg.eigh(subset_by_index=[0,1])).
-//
-//   * complete graph -> n, disconnected graph -> 0 (exact, one ballot per BFS level);
-//   * otherwise lambda2(G) = n - mu_max(complement of G): L(G) + L(G') = n I - J, so on
-//     the space orthogonal to the all-ones vector the spectra mirror each other.  Only
-//     the n' vertices that miss at least one neighbour carry edges of the complement;
-//     they are compacted to lanes 0..n'-1 and the n' x n' Laplacian of the complement is
-//     tridiagonalised by Householder reflections with row j held in the registers of
-//     lane j (no matrix in LDS), then mu_max is bracketed by 64-way multisection on
-//     the sign changes of the Sturm sequence of the tridiagonal matrix.
+// a[i] for a wave-uniform runtime i in [LO, HI): binary search by uniform branches.  (Publishing
+// the pivot row through LDS instead costs a 16-byte store per column pair for the whole wave and
+// made the LDS pipe the bottleneck.)
+template <int NPAD, int LO, int HI>
+__device__ __forceinline__ double column_of(const double (&a)[NPAD], int i) {
+    if constexpr (HI - LO == 1) {
+        double v = a[LO];
+        asm volatile("" : "+v"(v));      // opaque leaf: stops the compiler from rebuilding a dynamic a[i] (scratch array)
+        return v;
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (i < MID) return column_of<NPAD, LO, MID>(a, i);
+        return column_of<NPAD, MID, HI>(a, i);
+    }
+}
+
 // Sturm multisection for the largest eigenvalue of the symmetric tridiagonal matrix
-// (L.dd[0..np), L.e2[1..np)) inside [lo, hi]: lane t evaluates the Sturm sequence
+// (L.de[k] = (d_k, e_k^2), k < np) inside [lo, hi]: lane t evaluates the Sturm sequence
 // p_0 = 1, p_k = (d_k - x) p_{k-1} - e_k^2 p_{k-2} at x_t; its sign changes count the
 // eigenvalues below x_t.  Every round shrinks the bracket 65-fold.
 template <class LDS>
@@ -270,10 +276,11 @@ __device__ __forceinline__ double sturm_largest_wave(const LDS& L, int np, int l
         if (hi - lo <= 2e-12 * hi) break;
         const double w = (hi - lo) * (1.0 / 65.0);
         const double x = lo + w * (double)(lane + 1);
-        double pm = 1.0, pc = L.dd[0] - x;
+        double pm = 1.0, pc = L.de[0].x - x;
         int cnt = (unsigned)__double2hiint(pc) >> 31;
         for (int i = 1; i < np; ++i) {
-            const double pn = fma(L.dd[i] - x, pc, -(L.e2[i] * pm));
+            const double2 t = L.de[i];
+            const double pn = fma(t.x - x, pc, -(t.y * pm));
             cnt += ((unsigned)(__double2hiint(pn) ^ __double2hiint(pc))) >> 31;
             pm = pc;
             pc = pn;
@@ -314,39 +321,38 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
         a[c] = (c == lane) ? (double)cdeg : -(double)((crow >> c) & 1ull);
     });
 
-    // Row i of the symmetric matrix is also its column i: the pivot lane publishes its row in
-    // LDS (static register indices) and lane j picks element j.
-    ColBlocks<NPAD, 0>::dump_row(a, lane, np - 1, np - 1, L.urow);
-    WSYNC();
     for (int i = np - 1; i >= 2; --i) {
         const int l = i - 1;
-        const double col = L.urow[lane];                         // A[i][lane]
-        const double aii = L.urow[i];
+        const double col = column_of<NPAD, 0, NPAD>(a, i);       // A[lane][i] == A[i][lane]
+        const double aii = readlane_d(col, i);
         double uj = (lane <= l) ? col : 0.0;
         double h = wave_sum_dpp(uj * uj);
-        if (lane == 0) { L.dd[i] = aii; L.e2[i] = h; }
+        if (lane == 0) L.de[i] = make_double2(aii, h);
         // h == 0 (row already reduced): u = 0 and 1/h := 0 turn the step into a no-op that still
         // hands the next pivot row over
         const double f = readlane_d(uj, l);
-        const double g = (f >= 0.0) ? -sqrt(h) : sqrt(h);
+        const double sq = (h > 0.0) ? fast_sqrt(h) : 0.0;
+        const double g = (f >= 0.0) ? -sq : sq;
         const double h2 = h - f * g;
         if (lane == l) uj = f - g;
-        // p = A u / h : u_c reaches every lane through SGPRs
+        L.uvec[lane] = uj;
+        WSYNC();
+        // p = A u / h
         double p0 = 0.0, p1 = 0.0;
-        ColBlocks<NPAD, 0>::matvec(a, uj, l, p0, p1);
-        const double hinv = (h > 0.0) ? 1.0 / h2 : 0.0;
+        ColBlocks<NPAD, 0>::matvec(a, L.uvec, l, p0, p1);
+        const double hinv = (h > 0.0) ? fast_rcp(h2) : 0.0;
         const double p = (lane <= l) ? (p0 + p1) * hinv : 0.0;
         const double K = wave_sum_dpp(uj * p) * (0.5 * hinv);
         const double qj = (lane <= l) ? fma(-K, uj, p) : 0.0;
-        L.uq[lane] = make_double2(uj, qj);
+        L.qvec[lane] = qj;
         WSYNC();
-        // A -= u q^T + q u^T : (u_c, q_c) by one broadcast LDS read per column
-        ColBlocks<NPAD, 0>::update(a, uj, qj, lane, l, L.uq, L.urow);
+        // A -= u q^T + q u^T
+        ColBlocks<NPAD, 0>::update(a, uj, qj, l, L.uvec, L.qvec);
         WSYNC();
     }
     {
         const double a11 = readlane_d(a[1], 1), a10 = readlane_d(a[0], 1), a00 = readlane_d(a[0], 0);
-        if (lane == 0) { L.dd[1] = a11; L.e2[1] = a10 * a10; L.dd[0] = a00; L.e2[0] = 0.0; }
+        if (lane == 0) { L.de[1] = make_double2(a11, a10 * a10); L.de[0] = make_double2(a00, 0.0); }
     }
     WSYNC();
     const double lo = (double)(dmax + 1) * (1.0 - 1e-13) - 1e-13;
@@ -982,10 +988,8 @@ struct BigLds {
     static constexpr int NN = WAVE * S;
     double sx[NN], sy[NN];
     double jx[WAVE], jy[WAVE];
-    double2 uq[WAVE];
-    double dd[NN], e2[NN];
-    __attribute__((aligned(16))) double urow[WAVE];
-    double uvec[NN], qvec[NN];
+    double2 de[NN];
+    __attribute__((aligned(16))) double uvec[NN], qvec[NN];
     unsigned long long xfer[NN * S];
     double cx[NN + 2], cy[NN + 2], px[NN + 2], py[NN + 2];
     int csz[NN + 2];
@@ -1181,7 +1185,7 @@ __device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int 
         }
         const double h = wave_sum_dpp(hh);
         const double aii = readlane_d(own_i, i & (WAVE - 1));
-        if (lane == 0) { L.dd[i] = aii; L.e2[i] = h; }
+        if (lane == 0) L.de[i] = make_double2(aii, h);
         const double f = readlane_d(own_l, l & (WAVE - 1));
         const double g = (f >= 0.0) ? -sqrt(h) : sqrt(h);
         const double h2 = h - f * g;
@@ -1236,7 +1240,7 @@ __device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int 
         if (lane == 1) { a11 = As[(size_t)ld + 1]; a10 = As[1]; }
         if (lane == 0) a00 = As[0];
         a11 = readlane_d(a11, 1); a10 = readlane_d(a10, 1); a00 = readlane_d(a00, 0);
-        if (lane == 0) { L.dd[1] = a11; L.e2[1] = a10 * a10; L.dd[0] = a00; L.e2[0] = 0.0; }
+        if (lane == 0) { L.de[1] = make_double2(a11, a10 * a10); L.de[0] = make_double2(a00, 0.0); }
     }
     WSYNC();
     const double lo = (double)(dmax + 1) * (1.0 - 1e-13) - 1e-13;
