@@ -67,3 +67,21 @@ def test_batched_trainer_two_rollouts():
     assert out["total_rollouts"] == 2 and out["total_timesteps"] == 2 * 24 * 128
     assert tr.total_episodes == 2 * 128          # 48 steps of 20-step episodes: two ends per env
     assert np.isfinite(tr.agent.training_stats["actor_loss"][-1])
+
+
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+    """The N>1 code path of bench.py (rank sharding by env_offset, barrier, MAX-over-ranks timing,
+    one JSON line from rank 0) with two gloo ranks on the one visible GPU."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs-per-gpu", "512", "--backend", "gloo",
+           "--share-device"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert d["value"] > 0 and abs(d["value"] - 2 * 512 * 20 / (d["ms_per_step"] * 20e-3)) / d["value"] < 1e-6
