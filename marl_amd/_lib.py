@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmarl_env.so")
+LIB_PATH = os.environ.get("MARL_ENV_LIB") or os.path.join(_HERE, "libmarl_env.so")   # override: A/B builds
 
 NUM_BANDS = 4
 OBS_DIM = 5

@@ -161,8 +161,10 @@ __device__ __forceinline__ uint64_t jam_row(const WaveLds& L, int n, int m, int 
 // lanes with DPP moves, then the four row totals through SGPRs.
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    // every lane is written (full row and bank masks, rotations have no invalid source), so the
+    // previous content of the destination does not matter and needs no initialisation
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double readlane_d(double v, int src) {      // src wave-uniform
@@ -211,41 +213,55 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int NPAD, int B>
-struct ColBlocks {
-    // p += A[:, 8B..8B+7] * u[8B..8B+7]; (u_c, u_c+1) by one 16-byte broadcast LDS read
-    static __device__ __forceinline__ void matvec(const double (&a)[NPAD], const double* uvec, int l, double& p0, double& p1) {
-        if constexpr (B * 8 < NPAD) {
-            if (B * 8 > l) return;
-            static_for<0, 4>([&](auto k) {
-                constexpr int c = B * 8 + 2 * decltype(k)::value;
-                const double2 t = *reinterpret_cast<const double2*>(uvec + c);
-                p0 = fma(a[c], t.x, p0);
-                p1 = fma(a[c + 1], t.y, p1);
-            });
-            // pin the partial sums here (see update): keeps this block's loads behind its exit test
+// The broadcasts of u and q come from LDS as 16-byte reads of two neighbouring columns; the
+// reads of the next half block (4 columns) are issued before the arithmetic of the current one.
+// H counts half blocks; the exit test sits at every second one (never at the first: l >= 1).
+template <int NPAD, int H>
+struct ColHalves {
+    static constexpr int C0 = H * 4;
+    // p += A[:, 4H..4H+3] * v[4H..4H+3]; t = (v_4H, v_4H+1), (v_4H+2, v_4H+3) already loaded
+    static __device__ __forceinline__ void matvec(const double (&a)[NPAD], const double* uvec, int l,
+                                                  double& p0, double& p1, double2 t0, double2 t1) {
+        if constexpr (C0 < NPAD) {
+            if constexpr (H % 2 == 0 && H > 0) {
+                if (C0 > l) return;
+            }
+            double2 n0 = t0, n1 = t1;
+            if constexpr (C0 + 4 < NPAD) {
+                n0 = *reinterpret_cast<const double2*>(uvec + C0 + 4);
+                n1 = *reinterpret_cast<const double2*>(uvec + C0 + 6);
+            }
+            p0 = fma(a[C0], t0.x, p0);
+            p1 = fma(a[C0 + 1], t0.y, p1);
+            p0 = fma(a[C0 + 2], t1.x, p0);
+            p1 = fma(a[C0 + 3], t1.y, p1);
+            // pin the partial sums here: keeps the following reads behind the exit test
             asm volatile("" : "+v"(p0), "+v"(p1) :: "memory");
-            ColBlocks<NPAD, B + 1>::matvec(a, uvec, l, p0, p1);
+            ColHalves<NPAD, H + 1>::matvec(a, uvec, l, p0, p1, n0, n1);
         }
     }
-    // A[:, c] -= u q_c + q u_c with (u_c, u_c+1) and (q_c, q_c+1) by 16-byte broadcast LDS reads.
-    static __device__ __forceinline__ void update(double (&a)[NPAD], double uj, double qj, int l,
-                                                  const double* uvec, const double* qvec) {
-        if constexpr (B * 8 < NPAD) {
-            if (B * 8 > l) return;
-            static_for<0, 4>([&](auto k) {
-                constexpr int c = B * 8 + 2 * decltype(k)::value;
-                const double2 tu = *reinterpret_cast<const double2*>(uvec + c);
-                const double2 tq = *reinterpret_cast<const double2*>(qvec + c);
-                a[c] = fma(-uj, tq.x, fma(-qj, tu.x, a[c]));
-                a[c + 1] = fma(-uj, tq.y, fma(-qj, tu.y, a[c + 1]));
-            });
-            // pin this block's results here: without it the compiler issues every block's loads
-            // first and sinks all the arithmetic behind them, which needs 4 registers per column
-            asm volatile("" : "+v"(a[B * 8]), "+v"(a[B * 8 + 1]), "+v"(a[B * 8 + 2]), "+v"(a[B * 8 + 3]),
-                              "+v"(a[B * 8 + 4]), "+v"(a[B * 8 + 5]), "+v"(a[B * 8 + 6]), "+v"(a[B * 8 + 7])
-                         :: "memory");
-            ColBlocks<NPAD, B + 1>::update(a, uj, qj, l, uvec, qvec);
+    // A[:, c] -= u q_c + q u_c for c = 4H..4H+3; tu / tq = the u and q pairs of this half block
+    static __device__ __forceinline__ void update(double (&a)[NPAD], double uj, double qj, int l, const double* uvec,
+                                                  const double* qvec, double2 tu0, double2 tu1, double2 tq0, double2 tq1) {
+        if constexpr (C0 < NPAD) {
+            if constexpr (H % 2 == 0 && H > 0) {
+                if (C0 > l) return;
+            }
+            double2 nu0 = tu0, nu1 = tu1, nq0 = tq0, nq1 = tq1;
+            if constexpr (C0 + 4 < NPAD) {
+                nu0 = *reinterpret_cast<const double2*>(uvec + C0 + 4);
+                nq0 = *reinterpret_cast<const double2*>(qvec + C0 + 4);
+                nu1 = *reinterpret_cast<const double2*>(uvec + C0 + 6);
+                nq1 = *reinterpret_cast<const double2*>(qvec + C0 + 6);
+            }
+            a[C0] = fma(-uj, tq0.x, fma(-qj, tu0.x, a[C0]));
+            a[C0 + 1] = fma(-uj, tq0.y, fma(-qj, tu0.y, a[C0 + 1]));
+            a[C0 + 2] = fma(-uj, tq1.x, fma(-qj, tu1.x, a[C0 + 2]));
+            a[C0 + 3] = fma(-uj, tq1.y, fma(-qj, tu1.y, a[C0 + 3]));
+            // pin this half block's results here: without it the compiler issues every read first
+            // and sinks all the arithmetic behind them, which needs 4 registers per column
+            asm volatile("" : "+v"(a[C0]), "+v"(a[C0 + 1]), "+v"(a[C0 + 2]), "+v"(a[C0 + 3]) :: "memory");
+            ColHalves<NPAD, H + 1>::update(a, uj, qj, l, uvec, qvec, nu0, nu1, nq0, nq1);
         }
     }
 };
@@ -308,6 +324,17 @@ __device__ __forceinline__ double sturm_largest_wave(const LDS& L, int np, int l
 // rows are `crow` (lane j < np holds row j): Householder tridiagonalisation with row j in
 // the registers of lane j, then Sturm multisection inside the Laplacian bracket
 // [dmax + 1, min(np, 2 dmax)] (valid for a graph with at least one edge).
+#ifdef MARL_EXP_TIMING
+#define TSTAMP(k, pin)                                                                    \
+    do {                                                                                  \
+        uint64_t t_;                                                                      \
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(pin)::"memory"); \
+        tacc[k] += (double)(t_ - tlast);                                                  \
+        tlast = t_;                                                                       \
+    } while (0)
+#else
+#define TSTAMP(k, pin)
+#endif
 template <int NPAD, class LDS>
 __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int lane, LDS& L, int rounds) {
     const int cdeg = __popcll(crow);
@@ -321,12 +348,19 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
         a[c] = (c == lane) ? (double)cdeg : -(double)((crow >> c) & 1ull);
     });
 
+#ifdef MARL_EXP_TIMING
+    double tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tlast;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+#endif
     for (int i = np - 1; i >= 2; --i) {
         const int l = i - 1;
-        const double col = column_of<NPAD, 0, NPAD>(a, i);       // A[lane][i] == A[i][lane]
+        double col = column_of<NPAD, 0, NPAD>(a, i);       // A[lane][i] == A[i][lane]
+        TSTAMP(0, col);
         const double aii = readlane_d(col, i);
         double uj = (lane <= l) ? col : 0.0;
         double h = wave_sum_dpp(uj * uj);
+        TSTAMP(1, h);
         if (lane == 0) L.de[i] = make_double2(aii, h);
         // h == 0 (row already reduced): u = 0 and 1/h := 0 turn the step into a no-op that still
         // hands the next pivot row over
@@ -337,19 +371,39 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
         if (lane == l) uj = f - g;
         L.uvec[lane] = uj;
         WSYNC();
+        TSTAMP(2, uj);
         // p = A u / h
         double p0 = 0.0, p1 = 0.0;
-        ColBlocks<NPAD, 0>::matvec(a, L.uvec, l, p0, p1);
+        {
+            const double2 t0 = *reinterpret_cast<const double2*>(L.uvec), t1 = *reinterpret_cast<const double2*>(L.uvec + 2);
+            ColHalves<NPAD, 0>::matvec(a, L.uvec, l, p0, p1, t0, t1);
+        }
+        TSTAMP(3, p0);
         const double hinv = (h > 0.0) ? fast_rcp(h2) : 0.0;
-        const double p = (lane <= l) ? (p0 + p1) * hinv : 0.0;
+        double p = (lane <= l) ? (p0 + p1) * hinv : 0.0;
+        TSTAMP(4, p);
         const double K = wave_sum_dpp(uj * p) * (0.5 * hinv);
-        const double qj = (lane <= l) ? fma(-K, uj, p) : 0.0;
+        double qj = (lane <= l) ? fma(-K, uj, p) : 0.0;
+        // A -= u q^T + q u^T
         L.qvec[lane] = qj;
         WSYNC();
-        // A -= u q^T + q u^T
-        ColBlocks<NPAD, 0>::update(a, uj, qj, l, L.uvec, L.qvec);
+        TSTAMP(5, qj);
+        {
+            const double2 tu0 = *reinterpret_cast<const double2*>(L.uvec), tu1 = *reinterpret_cast<const double2*>(L.uvec + 2);
+            const double2 tq0 = *reinterpret_cast<const double2*>(L.qvec), tq1 = *reinterpret_cast<const double2*>(L.qvec + 2);
+            ColHalves<NPAD, 0>::update(a, uj, qj, l, L.uvec, L.qvec, tu0, tu1, tq0, tq1);
+        }
+        TSTAMP(6, a[0]);
         WSYNC();
+        TSTAMP(7, a[1]);
     }
+#ifdef MARL_EXP_TIMING
+    {
+        double r_ = 0.0;
+        static_for<0, 8>([&](auto k) { if ((blockIdx.x & 7) == decltype(k)::value) r_ = tacc[decltype(k)::value]; });
+        return r_;
+    }
+#endif
     {
         const double a11 = readlane_d(a[1], 1), a10 = readlane_d(a[0], 1), a00 = readlane_d(a[0], 0);
         if (lane == 0) { L.de[1] = make_double2(a11, a10 * a10); L.de[0] = make_double2(a00, 0.0); }
