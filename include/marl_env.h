@@ -28,6 +28,8 @@
  *   assign                                 int32  [E][M]    jammer_assignments: cluster id per jammer,
  *                                                            -1 noise pseudo-cluster, -2 none
  *   workspace                              double [E][ld][ld] scratch of the lambda2 solver, N > 64 only
+ *   solve_*                                scratch that carries an env from the front half of a step to its
+ *                                          eigen-solve, N <= 64 only (see MarlEnvState)
  */
 #ifndef MARL_ENV_H
 #define MARL_ENV_H
@@ -91,6 +93,17 @@ typedef struct MarlEnvState {
     int32_t *prev_n_clusters, *prev_ncent;
     int32_t *assign;
     double *workspace;         /* lambda2 scratch, [E][ld][ld] with ld = N rounded up to 8; NULL when N <= 64 */
+    /* N <= 64: a step runs as three launches.  The front kernel does everything but the eigen-solve and
+     * leaves, for the envs whose graph is neither complete nor disconnected, the compacted complement
+     * rows; the order kernel sorts those envs by matrix size, largest first; the solve kernel works
+     * through them in that order (longest job first keeps the CUs evenly loaded) and finishes the reward.
+     * The buffers must be zero before the first step; a step leaves solve_hist zero again. */
+    uint64_t *solve_rows;      /* [E][64] complement adjacency row per compacted vertex */
+    int32_t *solve_np;         /* [E] vertices in the eigenproblem, 0 = lambda2 already final */
+    int32_t *solve_slot;       /* [E] rank of the env among those with the same solve_np */
+    int32_t *solve_perm;       /* [E] env indices, largest eigenproblem first */
+    int32_t *solve_hist;       /* [128] envs per solve_np (bins 0..64); [65] = envs to solve in this step */
+    double *solve_partial;     /* [E][4] reward terms 2..5 awaiting the lambda2 term */
 } MarlEnvState;
 
 /* Inputs and outputs of one step.  Optional pointers may be NULL. */

@@ -42,6 +42,7 @@ _STATE_ARRAYS = [
     "enemy_x", "enemy_y", "enemy_vx", "enemy_vy", "jam_x", "jam_y", "jam_band", "last_vx", "last_vy",
     "step_count", "enemy_band", "lambda2_initial", "labels", "cent_x", "cent_y", "cent_size",
     "n_clusters", "ncent", "prev_x", "prev_y", "prev_n_clusters", "prev_ncent", "assign", "workspace",
+    "solve_rows", "solve_np", "solve_slot", "solve_perm", "solve_hist", "solve_partial",
 ]
 
 

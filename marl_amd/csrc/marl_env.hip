@@ -49,6 +49,15 @@ thread_local int g_last_hip_error = 0;
 // ------------------------------------------------------------------ wave helpers
 #define WSYNC() __syncthreads()   /* workgroup == one wave */
 
+// f(integral_constant<0>) ... f(integral_constant<E-1>): a loop whose index is a constant when parsed
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p ? 1 : 0); }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -108,6 +117,7 @@ __device__ __forceinline__ void noise_pair(uint64_t seed, uint64_t genv, uint32_
 // ------------------------------------------------------------------ LDS layout of one env
 struct WaveLds {
     double sx[WAVE], sy[WAVE];        // enemy positions
+    double2 sxy[WAVE];                // the same, interleaved: one 16-byte read per enemy in the pair loop
     double jx[WAVE], jy[WAVE];        // jammer positions
     __attribute__((aligned(16))) double uvec[WAVE], qvec[WAVE];   // Householder vectors u, q
     double2 de[WAVE];                 // tridiagonal: (diagonal, squared off-diagonal) per row
@@ -154,6 +164,77 @@ __device__ __forceinline__ uint64_t jam_row(const WaveLds& L, int n, int m, int 
     }
     row &= ~(1ull << lane);
     return lane < n ? row : 0ull;
+}
+
+// Both rows in one pass over the enemies (step kernel; needs L.sxy).  The jamming test is evaluated
+// in a scaled form that rounds exactly like the reference's: with s = fl(xi + xj),
+//   fl(qx - s/2) = fl(2qx - s) / 2,   so   fl(dx^2 + dy^2) <= d2max  <=>  fl(DX^2 + DY^2) <= 4 d2max
+// for DX = fl(2qx - s) (halving and doubling are exact), which shares s between the jammers and
+// drops two multiplications per pair.  KJ = matching jammers handled in this pass (their doubled
+// coordinates in q2x / q2y); ADJ = also build the adjacency row.
+template <int KJ, bool ADJ>
+__device__ __forceinline__ void pair_pass(const WaveLds& L, int n, int lane, double thr_comm, double thr_jam4,
+                                          const double (&q2x)[4], const double (&q2y)[4], uint64_t& adj, uint64_t& jam) {
+    const double2 pi = L.sxy[lane & (WAVE - 1)];
+    uint32_t a_lo = 0, a_hi = 0, j_lo = 0, j_hi = 0;
+    auto body = [&](int j, uint32_t bit, uint32_t& a, uint32_t& jm) {
+        const double2 pj = L.sxy[j];
+        if constexpr (ADJ) {
+            const double dx = pi.x - pj.x, dy = pi.y - pj.y;
+            a |= (dx * dx + dy * dy <= thr_comm) ? bit : 0u;
+        }
+        if constexpr (KJ > 0) {
+            const double sx = pi.x + pj.x, sy = pi.y + pj.y;
+            bool hit = false;
+            static_for<0, KJ>([&](auto k) {
+                const double DX = q2x[decltype(k)::value] - sx, DY = q2y[decltype(k)::value] - sy;
+                hit |= (DX * DX + DY * DY <= thr_jam4);
+            });
+            jm |= hit ? bit : 0u;
+        }
+    };
+    const int n_lo = n < 32 ? n : 32;
+    for (int j = 0; j < n_lo; ++j) body(j, 1u << j, a_lo, j_lo);
+    for (int j = 32; j < n; ++j) body(j, 1u << (j - 32), a_hi, j_hi);
+    const uint64_t keep = (lane < n) ? ~(1ull << lane) : 0ull;
+    if constexpr (ADJ) adj = (((uint64_t)a_hi << 32) | a_lo) & keep;
+    jam |= (((uint64_t)j_hi << 32) | j_lo) & keep;
+}
+
+// Adjacency row (communication_graph.py:41-105) and disrupted-links row (jamming.py:151-247) of
+// enemy `lane`: the first four matching jammers share the adjacency pass, further ones (rare) take
+// extra passes of four, padded with jammers that reach nothing.
+__device__ __forceinline__ void pair_rows(const WaveLds& L, int n, int m, int lane, int eband, double d2_comm,
+                                          double d2_jam, uint64_t& adj, uint64_t& jam) {
+    uint64_t mm = ballot64(lane < m && L.jb[lane & (WAVE - 1)] == eband);
+    const int cnt = __popcll(mm);
+    const double thr4 = 4.0 * d2_jam;
+    double q2x[4], q2y[4];
+    auto next_four = [&]() {
+        static_for<0, 4>([&](auto k) {
+            double x = 1e300, y = 1e300;           // squares overflow to +inf: never within range
+            if (mm) {
+                const int j = __ffsll((unsigned long long)mm) - 1;
+                mm &= mm - 1;
+                x = 2.0 * L.jx[j]; y = 2.0 * L.jy[j];
+            }
+            q2x[decltype(k)::value] = x; q2y[decltype(k)::value] = y;
+        });
+    };
+    adj = 0; jam = 0;
+    next_four();
+    switch (cnt < 4 ? cnt : 4) {
+        case 0: pair_pass<0, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+        case 1: pair_pass<1, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+        case 2: pair_pass<2, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+        case 3: pair_pass<3, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+        default: pair_pass<4, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+    }
+    while (mm) {
+        next_four();
+        uint64_t dummy;
+        pair_pass<4, false>(L, n, lane, d2_comm, thr4, q2x, q2y, dummy, jam);
+    }
 }
 
 // ------------------------------------------------------------------ lambda2
@@ -205,13 +286,6 @@ __device__ __forceinline__ double fast_sqrt(double x) {
 // keep the array in scratch memory): loops are expanded by template recursion, in blocks
 // of 8 columns with a wave-uniform exit after the block that holds column l.  Columns
 // l+1.. of the last block are no-ops because u and q are zero there.
-template <int I, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < E) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, E>(f);
-    }
-}
 
 // The broadcasts of u and q come from LDS as 16-byte reads of two neighbouring columns; the
 // reads of the next half block (4 columns) are issued before the arithmetic of the current one.
@@ -423,13 +497,15 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
 //     the space orthogonal to the all-ones vector the spectra mirror each other.  Only
 //     the n' vertices that miss at least one neighbour carry edges of the complement;
 //     they are compacted to lanes 0..n'-1 and handed to mu_max_compact_wave.
-template <int NPAD>
-__device__ __forceinline__ double lambda2_wave(uint64_t row, int n, int lane, WaveLds& L, int rounds) {
-    if (n <= 1) return 0.0;
+// Everything before the eigen-solve: returns true when lambda2 is already known (in `lam`),
+// false when the complement rows `crow` of the np compacted vertices have to be solved.
+__device__ __forceinline__ bool lambda2_prepare(uint64_t row, int n, int lane, WaveLds& L, double& lam, uint64_t& crow, int& np) {
+    crow = 0; np = 0; lam = 0.0;
+    if (n <= 1) return true;
     const int deg = __popcll(row);
     const uint64_t active = (n >= 64) ? ~0ull : ((1ull << n) - 1);
     const uint64_t touched = ballot64(lane < n && deg < n - 1);
-    if (touched == 0) return (double)n;
+    if (touched == 0) { lam = (double)n; return true; }
     {   // connectivity: breadth-first search from vertex 0
         uint64_t comp = 1ull, frontier = 1ull;
         while (frontier) {
@@ -438,26 +514,37 @@ __device__ __forceinline__ double lambda2_wave(uint64_t row, int n, int lane, Wa
             comp |= nw;
             frontier = nw;
         }
-        if (comp != active) return 0.0;
+        if (comp != active) return true;
     }
     // complement rows restricted to the touched vertices, compacted
-    const int np = __popcll(touched);
+    np = __popcll(touched);
     const uint64_t crow_full = ~row & active & ~(1ull << lane) & touched;
-    uint64_t crow = 0;
-    {
+    {   // one step per run of consecutive touched vertices
         uint64_t t = touched;
         int k = 0;
         while (t) {
-            const int v = __ffsll((unsigned long long)t) - 1;
-            crow |= ((crow_full >> v) & 1ull) << k;
-            t &= t - 1;
-            ++k;
+            const int a = __ffsll((unsigned long long)t) - 1;
+            const uint64_t inv = ~(t >> a);                      // zero bits mark the end of the run
+            const int len = inv ? __ffsll((unsigned long long)inv) - 1 : 64;
+            const uint64_t ones = (len >= 64) ? ~0ull : ((1ull << len) - 1);
+            crow |= ((crow_full >> a) & ones) << k;
+            k += len;
+            t = (a + len >= 64) ? 0ull : (t & ~(ones << a));
         }
     }
     WSYNC();
     if ((touched >> lane) & 1ull) L.xfer[__popcll(touched & ((1ull << lane) - 1))] = crow;
     WSYNC();
     crow = (lane < np) ? L.xfer[lane] : 0ull;
+    return false;
+}
+
+template <int NPAD>
+__device__ __forceinline__ double lambda2_wave(uint64_t row, int n, int lane, WaveLds& L, int rounds) {
+    double lam;
+    uint64_t crow;
+    int np;
+    if (lambda2_prepare(row, n, lane, L, lam, crow, np)) return lam;
     return (double)n - mu_max_compact_wave<NPAD>(crow, np, lane, L, rounds);
 }
 
@@ -568,7 +655,21 @@ __device__ __forceinline__ void assign_proportional_wave(int m, int lane, LDS& L
 }
 
 // ------------------------------------------------------------------ reward + observation
-struct RewardOut { double total; float r0, r1, r2, r3, r4; float o0, o1, o2, o3, o4; };
+struct RewardOut { double total; double d2, d3, d5; float r0, r1, r2, r3, r4; float o0, o1, o2, o3, o4; };
+
+// Term 1 (reward.py:178-199) and the clipped weighted sum (reward.py:282-306) from the four terms
+// that do not depend on lambda2.
+__device__ __forceinline__ double reward_total(const MarlEnvParams& P, double lam, double lam0, double r2, double r3,
+                                               float r4, double r5, double& r1) {
+    r1 = 0.0;
+    if (lam0 > 0.0) {
+        const double lc = lam > 0.0 ? lam : 0.0;
+        r1 = 1.0 - (lc / lam0);
+        r1 = fmin(fmax(r1, 0.0), 1.0);
+    }
+    const double raw = P.omega[0] * r1 + P.omega[1] * r2 + P.omega[2] * r3 - P.omega[3] * (double)r4 - P.omega[4] * r5;
+    return fmin(fmax(raw, -10.0), 10.0);
+}
 
 // RewardCalculator.compute (reward.py:106-306) and ObservationBuilder.build_vectorized
 // (observation.py:264-332).  Lane j < m owns jammer j.  obs_row receives the five
@@ -604,13 +705,6 @@ __device__ __forceinline__ RewardOut reward_obs_wave(const MarlEnvParams& P, int
     const double r5 = (m > 1) ? (double)ovl / ((double)(m * (m - 1)) / 2) : 0.0;
     const int match = (act && L.jb[lane & (WAVE - 1)] == eband) ? 1 : 0;
     const int nmatch = wave_sum(match);
-    // term 1 (reward.py:178-199)
-    double r1 = 0.0;
-    if (lam0 > 0.0) {
-        const double lc = lam > 0.0 ? lam : 0.0;
-        r1 = 1.0 - (lc / lam0);
-        r1 = fmin(fmax(r1, 0.0), 1.0);
-    }
     const double r2 = (double)nmatch / (double)m;
     // term 3 (reward.py:218-260): assigned centroid if its id still exists, else nearest
     double prox = 0.0;
@@ -627,8 +721,9 @@ __device__ __forceinline__ RewardOut reward_obs_wave(const MarlEnvParams& P, int
     float en = 0.0f;
     if (act) en = (raw_vx * raw_vx + raw_vy * raw_vy) / P.v_max_sq_f32;
     const float r4 = wave_sum(en) / (float)m;
-    const double raw = P.omega[0] * r1 + P.omega[1] * r2 + P.omega[2] * r3 - P.omega[3] * (double)r4 - P.omega[4] * r5;
-    out.total = fmin(fmax(raw, -10.0), 10.0);
+    double r1;
+    out.total = reward_total(P, lam, lam0, r2, r3, r4, r5, r1);
+    out.d2 = r2; out.d3 = r3; out.d5 = r5;
     out.r0 = (float)r1; out.r1 = (float)r2; out.r2 = (float)r3; out.r3 = r4; out.r4 = (float)r5;
     // observation
     out.o0 = (float)fmin(fmax(best / A, 0.0), 1.0);
@@ -680,9 +775,16 @@ __device__ __forceinline__ void store_bits(uint32_t* dst, int e, int n, int lane
 
 __device__ __forceinline__ WaveLds& carve(unsigned char* smem) { return *reinterpret_cast<WaveLds*>(smem); }
 
-// ------------------------------------------------------------------ step kernel (N <= 64)
-template <int NPAD>
-__global__ __launch_bounds__(WAVE) void env_step_wave_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
+// ------------------------------------------------------------------ step kernels (N <= 64)
+// A step is three launches.  The duration of the eigen-solve depends on the graph (nothing for a
+// complete or disconnected graph, O(n'^3) otherwise), and a fused kernel, which can only take the
+// envs in index order, leaves most SIMDs idle while the last long solves finish.  Split like this
+// the cheap, uniform part runs at the occupancy its small register footprint allows, and the
+// solves are started longest first.
+enum { SOLVE_HIST_TOTAL = 65, SOLVE_HIST_WORDS = 128 };
+
+// Front half: everything of JammerEnv.step but the eigen-solve.
+__global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds& L = carve(smem);
     const int e = blockIdx.x, lane = threadIdx.x;
@@ -733,6 +835,7 @@ __global__ __launch_bounds__(WAVE) void env_step_wave_kernel(MarlEnvParams P, Ma
         y = fmin(fmax(y, 0.0), arena);
         S.enemy_x[o] = x; S.enemy_y[o] = y; S.enemy_vx[o] = vx; S.enemy_vy[o] = vy;
         L.sx[lane] = x; L.sy[lane] = y;
+        L.sxy[lane] = make_double2(x, y);
     }
     int num = S.n_clusters[e], ncent = S.ncent[e];
     WSYNC();
@@ -771,11 +874,14 @@ __global__ __launch_bounds__(WAVE) void env_step_wave_kernel(MarlEnvParams P, Ma
         WSYNC();
     }
     // -- lambda2 of the jammed graph (jammer_env.py:464-508)
-    const uint64_t adj = adjacency_row(L, n, lane, P.comm_d2_max[eband]);
-    const uint64_t jam = jam_row(L, n, m, lane, eband, P.jam_d2_max[eband]);
+    uint64_t adj, jam;
+    pair_rows(L, n, m, lane, eband, P.comm_d2_max[eband], P.jam_d2_max[eband], adj, jam);
     store_bits(io.adj_bits, e, n, lane, adj);
     store_bits(io.jam_bits, e, n, lane, jam);
-    const double lam = lambda2_wave<NPAD>(adj & ~jam, n, lane, L, P.lambda2_rounds);
+    double lam;
+    uint64_t crow;
+    int np;
+    const bool final_lam = lambda2_prepare(adj & ~jam, n, lane, L, lam, crow, np);
     const double lam0 = S.lambda2_initial[e];
     // -- reward, observation (jammer_env.py:414-438)
     const RewardOut rw = reward_obs_wave(P, n, m, lane, L, eband, num, ncent, lam, lam0, raw_vx, raw_vy);
@@ -789,12 +895,72 @@ __global__ __launch_bounds__(WAVE) void env_step_wave_kernel(MarlEnvParams P, Ma
     }
     double avgp = 0.0;
     if (io.avg_power_dbm) avgp = avg_power_wave(P, n, m, lane, L, eband);
+    if (!final_lam && lane < np) S.solve_rows[(size_t)e * WAVE + lane] = crow;
     if (lane == 0) {
         S.step_count[e] = step;
-        io.reward[e] = (float)rw.total;
         io.truncated[e] = (uint8_t)(step >= P.max_steps);
-        if (io.lambda2) io.lambda2[e] = lam;
         if (io.avg_power_dbm) io.avg_power_dbm[e] = avgp;
+        S.solve_np[e] = np;
+        if (final_lam) {
+            io.reward[e] = (float)rw.total;
+            if (io.lambda2) io.lambda2[e] = lam;
+        } else {
+            S.solve_slot[e] = atomicAdd(&S.solve_hist[np], 1);
+            double* part = S.solve_partial + (size_t)e * 4;
+            part[0] = rw.d2; part[1] = rw.d3; part[2] = (double)rw.r3; part[3] = rw.d5;
+        }
+    }
+}
+
+// Order: env indices of the pending solves into solve_perm, largest matrix first (a counting sort
+// over the histogram the front kernel built).  Every block derives the bin offsets itself.
+__global__ __launch_bounds__(1024) void solve_order_kernel(int E, MarlEnvState S) {
+    __shared__ int start[WAVE + 1];
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = WAVE; b >= 1; --b) { start[b] = acc; acc += S.solve_hist[b]; }
+        start[0] = acc;
+        if (blockIdx.x == 0) S.solve_hist[SOLVE_HIST_TOTAL] = acc;
+    }
+    __syncthreads();
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) {
+        const int np = S.solve_np[e];
+        if (np > 0) S.solve_perm[start[np] + S.solve_slot[e]] = e;
+    }
+}
+
+struct SolveLds {
+    __attribute__((aligned(16))) double uvec[WAVE], qvec[WAVE];
+    double2 de[WAVE];
+};
+
+// Solve: block b takes the b-th largest pending eigenproblem, then finishes that env's reward.
+template <int NPAD>
+__global__ __launch_bounds__(WAVE) void env_step_solve_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
+    __shared__ SolveLds L;
+    const int lane = threadIdx.x;
+    const int total = S.solve_hist[SOLVE_HIST_TOTAL];
+    if ((int)blockIdx.x >= total) {
+        // the histogram has been consumed by the order kernel: the last block clears it for the next step
+        // (bins only: the other blocks of this launch still read the total)
+        if (blockIdx.x == gridDim.x - 1) {
+            S.solve_hist[lane] = 0;
+            if (lane == 0) S.solve_hist[WAVE] = 0;
+        }
+        return;
+    }
+    const int e = S.solve_perm[blockIdx.x];
+    const int np = S.solve_np[e];
+    const uint64_t crow = (lane < np) ? S.solve_rows[(size_t)e * WAVE + lane] : 0ull;
+    const double lam = (double)P.N - mu_max_compact_wave<NPAD>(crow, np, lane, L, P.lambda2_rounds);
+    if (lane == 0) {
+        const double* part = S.solve_partial + (size_t)e * 4;
+        double r1;
+        const double total_r = reward_total(P, lam, S.lambda2_initial[e], part[0], part[1], (float)part[2], part[3], r1);
+        io.reward[e] = (float)total_r;
+        if (io.lambda2) io.lambda2[e] = lam;
+        if (io.reward_terms) io.reward_terms[(size_t)e * 5] = (float)r1;
     }
 }
 
@@ -1879,6 +2045,12 @@ size_t marl_state_bytes(const MarlEnvParams* p, int32_t E) {
     b += 2 * align256(e * 4);            // prev_n_clusters, prev_ncent
     b += align256(e * m * 4);            // assign
     b += align256(workspace_bytes(p->N, E)); // lambda2 matrix workspace (N > 64 only)
+    if (p->N <= WAVE) {                      // hand-over from the front kernel to the solve kernel
+        b += align256(e * WAVE * 8);         // solve_rows
+        b += 3 * align256(e * 4);            // solve_np, solve_slot, solve_perm
+        b += align256(SOLVE_HIST_WORDS * 4); // solve_hist
+        b += align256(e * 4 * 8);            // solve_partial
+    }
     return b;
 }
 
@@ -1907,6 +2079,13 @@ int marl_state_bind(MarlEnvState* s, const MarlEnvParams* p, int32_t E, void* ba
     s->assign = (int32_t*)take(e * m * 4);
     const size_t wsb = workspace_bytes(p->N, E);
     s->workspace = wsb ? (double*)take(wsb) : nullptr;
+    const bool split = p->N <= WAVE;
+    s->solve_rows = split ? (uint64_t*)take(e * WAVE * 8) : nullptr;
+    s->solve_np = split ? (int32_t*)take(e * 4) : nullptr;
+    s->solve_slot = split ? (int32_t*)take(e * 4) : nullptr;
+    s->solve_perm = split ? (int32_t*)take(e * 4) : nullptr;
+    s->solve_hist = split ? (int32_t*)take(SOLVE_HIST_WORDS * 4) : nullptr;
+    s->solve_partial = split ? (double*)take(e * 4 * 8) : nullptr;
     return MARL_OK;
 }
 
@@ -1922,7 +2101,13 @@ int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepI
         MARL_DISPATCH_SLOTS(p->N, env_step_big_kernel, dim3(s->E), stream, *p, *s, *io);
         return hip_check(hipGetLastError());
     }
-    MARL_DISPATCH_NPAD(p->N, env_step_wave_kernel, dim3(s->E), wave_lds_bytes(p->N), stream, *p, *s, *io);
+    if (s->solve_rows == nullptr || s->solve_np == nullptr || s->solve_slot == nullptr || s->solve_perm == nullptr ||
+        s->solve_hist == nullptr || s->solve_partial == nullptr)
+        return MARL_EINVAL;
+    hipLaunchKernelGGL(env_step_front_kernel, dim3(s->E), dim3(WAVE), wave_lds_bytes(p->N), (hipStream_t)stream, *p, *s, *io);
+    hipLaunchKernelGGL(solve_order_kernel, dim3((s->E + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, (int)s->E, *s);
+    // one block more than envs: the last one never has a solve and clears the histogram
+    MARL_DISPATCH_NPAD(p->N, env_step_solve_kernel, dim3(s->E + 1), 0, stream, *p, *s, *io);
     return hip_check(hipGetLastError());
 }
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header_layout():
     # 8 int32 + 19 double + 12 double + 4 float
     assert C.sizeof(_lib.MarlEnvParams) == 8 * 4 + 31 * 8 + 4 * 4
-    assert C.sizeof(_lib.MarlEnvState) == 8 + 24 * 8
+    assert C.sizeof(_lib.MarlEnvState) == 8 + 30 * 8
     assert C.sizeof(_lib.MarlStepIO) == 12 * 8
     assert C.sizeof(_lib.MarlResetIO) == 10 * 8
 
@@ -77,6 +77,7 @@ def test_state_carving_is_disjoint_and_aligned():
     base = 0x10000000
     _lib.check(lib.marl_state_bind(C.byref(st), C.byref(p), E, C.c_void_p(base)))
     assert st.workspace is None                       # N <= 64 needs no lambda2 scratch
+    assert st.solve_rows is not None and st.solve_partial is not None
     ptrs = sorted(getattr(st, n) for n in _lib._STATE_ARRAYS if n != "workspace")
     assert ptrs[0] == base and all(q % 256 == 0 for q in ptrs)
     assert len(set(ptrs)) == len(ptrs) and ptrs[-1] < base + nbytes
@@ -86,6 +87,7 @@ def test_state_carving_is_disjoint_and_aligned():
     assert lib.marl_lambda2_workspace_bytes(200, E) == E * 200 * 200 * 8 and n2 > E * 200 * 200 * 8
     _lib.check(lib.marl_state_bind(C.byref(st), C.byref(p2), E, C.c_void_p(base)))
     assert st.workspace is not None and st.workspace + E * 200 * 200 * 8 <= base + n2
+    assert st.solve_rows is None                      # the three-launch step is for N <= 64
     assert lib.marl_state_bind(C.byref(st), C.byref(p), E, C.c_void_p(base + 8)) == _lib.MARL_EINVAL
 
 
