@@ -260,6 +260,21 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     v += dpp_mov<0x121>(v);      // row_ror:1
     return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
+// The same when only lanes 0..last hold non-zero terms (last wave-uniform): rows of 16 lanes
+// beyond `last` are not visited.
+__device__ __forceinline__ double wave_sum_dpp_upto(double v, int last) {
+    v += dpp_mov<0x128>(v);
+    v += dpp_mov<0x124>(v);
+    v += dpp_mov<0x122>(v);
+    v += dpp_mov<0x121>(v);
+    if (last < 16) return readlane_d(v, 0);
+    double t = v + readlane_d(v, 16);            // meaningful in lanes 0..15
+    if (last >= 32) {
+        t += readlane_d(v, 32);
+        t += readlane_d(v, 48);
+    }
+    return readlane_d(t, 0);
+}
 
 // 1/x and sqrt(x) (x > 0) from the hardware seeds (v_rcp_f64 / v_rsq_f64, about 23 good bits)
 // and two Newton / Goldschmidt steps: accurate to an ulp or two, a third of the instructions of
@@ -433,7 +448,7 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
         TSTAMP(0, col);
         const double aii = readlane_d(col, i);
         double uj = (lane <= l) ? col : 0.0;
-        double h = wave_sum_dpp(uj * uj);
+        double h = wave_sum_dpp_upto(uj * uj, l);
         TSTAMP(1, h);
         if (lane == 0) L.de[i] = make_double2(aii, h);
         // h == 0 (row already reduced): u = 0 and 1/h := 0 turn the step into a no-op that still
@@ -456,8 +471,8 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
         const double hinv = (h > 0.0) ? fast_rcp(h2) : 0.0;
         double p = (lane <= l) ? (p0 + p1) * hinv : 0.0;
         TSTAMP(4, p);
-        const double K = wave_sum_dpp(uj * p) * (0.5 * hinv);
-        double qj = (lane <= l) ? fma(-K, uj, p) : 0.0;
+        const double K = wave_sum_dpp_upto(uj * p, l) * (0.5 * hinv);
+        double qj = fma(-K, uj, p);                         // lanes > l: u = p = 0
         // A -= u q^T + q u^T
         L.qvec[lane] = qj;
         WSYNC();
@@ -916,11 +931,17 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
 // over the histogram the front kernel built).  Every block derives the bin offsets itself.
 __global__ __launch_bounds__(1024) void solve_order_kernel(int E, MarlEnvState S) {
     __shared__ int start[WAVE + 1];
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int b = WAVE; b >= 1; --b) { start[b] = acc; acc += S.solve_hist[b]; }
-        start[0] = acc;
-        if (blockIdx.x == 0) S.solve_hist[SOLVE_HIST_TOTAL] = acc;
+    if (threadIdx.x < WAVE) {                        // lane i stands for bin 64 - i: largest matrices first
+        const int bin = WAVE - (int)threadIdx.x;
+        const int own = S.solve_hist[bin];
+        int incl = own;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if ((int)threadIdx.x >= o) incl += up;
+        }
+        start[bin] = incl - own;
+        if (blockIdx.x == 0 && threadIdx.x == WAVE - 1) S.solve_hist[SOLVE_HIST_TOTAL] = incl;
     }
     __syncthreads();
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
