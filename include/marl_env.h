@@ -46,6 +46,8 @@ extern "C" {
 #define MARL_ASSIGN_NONE (-2)
 #define MARL_MAX_N 256          /* enemies per env supported by the kernels */
 #define MARL_MAX_M 64           /* jammers per env */
+#define MARL_ENEMY_RANDOM_WALK 0        /* EnemySwarm._step_random_walk, enemy_swarm.py:157-189 */
+#define MARL_ENEMY_COORDINATED_TURN 1   /* EnemySwarm._step_coordinated_turn, enemy_swarm.py:191-242 */
 
 enum {
     MARL_OK = 0,
@@ -65,10 +67,13 @@ typedef struct MarlEnvParams {
     int32_t random_jammer_start;
     int32_t max_reset_attempts;
     int32_t lambda2_rounds;          /* multisection rounds of the eigenvalue search (0 = default) */
+    int32_t enemy_mode;              /* MARL_ENEMY_RANDOM_WALK or MARL_ENEMY_COORDINATED_TURN (jammer_env.py:103) */
+    int32_t pad_i32;
     double arena_size, dt, v_max, v_enemy;
     double P_tx_w, P_sens_w, P_jam_w, P_thr_w;
     double omega[5];
     double kappa, eps, drift_threshold, spread, noise_std, min_lambda2_initial;
+    double omega_max;                /* turn-rate bound of the coordinated-turn model (enemy_swarm.py:60) */
     /* ---- derived by marl_params_init ---- */
     double comm_d2_max[MARL_NUM_BANDS];  /* largest squared distance with P_R >= P_sens, per enemy band */
     double jam_d2_max[MARL_NUM_BANDS];   /* largest squared jammer-midpoint distance with P_jam >= P_thr */
@@ -80,6 +85,7 @@ typedef struct MarlEnvState {
     int32_t E;
     int32_t pad;
     double *enemy_x, *enemy_y, *enemy_vx, *enemy_vy;
+    double *enemy_omega;       /* [E][N] turn rate per drone (coordinated turn; unused by the random walk) */
     double *jam_x, *jam_y;
     int32_t *jam_band;
     float *last_vx, *last_vy;
@@ -109,8 +115,9 @@ typedef struct MarlEnvState {
 /* Inputs and outputs of one step.  Optional pointers may be NULL. */
 typedef struct MarlStepIO {
     const float *actions;      /* [E][M][3]  (vx, vy, band) as the (M,3) action array, jammer_env.py:376-378 */
-    const double *noise;       /* [E][N][2]  enemy velocity noise draw (enemy_swarm.py:165); NULL = counter-based
-                                  generator keyed by (seed, env, step_count) */
+    const double *noise;       /* [E][N][2]  enemy velocity noise draw (enemy_swarm.py:165); coordinated turn:
+                                  [e][i][0] = the turn-rate draw of drone i (enemy_swarm.py:228), [e][i][1] unused.
+                                  NULL = counter-based generator keyed by (seed, env, step_count) */
     float *obs;                /* [E][M][5]  out */
     float *reward;             /* [E]        out */
     uint8_t *truncated;        /* [E]        out: step_count >= max_steps */
@@ -131,6 +138,7 @@ typedef struct MarlResetIO {
     const uint8_t *mask;       /* [E] reset env e iff mask[e] != 0; NULL = all */
     const double *enemy_pos;   /* [E][N][2] */
     const double *enemy_vel;   /* [E][N][2] */
+    const double *enemy_omega; /* [E][N] coordinated turn only (enemy_swarm.py:133-137); NULL = drawn on the device */
     const int32_t *enemy_band; /* [E] */
     const double *jam_init;    /* [E][M][2] positions (random_jammer_start) or centroid offsets */
     const int32_t *jam_band;   /* [E][M] */
@@ -160,7 +168,7 @@ int marl_last_hip_error(void);
 /* ---- the hot path --------------------------------------------------------- */
 
 /* JammerEnv.step for E envs in lockstep (environment/jammer_env.py:356-457):
- * action decode, enemy random walk, DBSCAN every K_recompute steps with drift
+ * action decode, enemy dynamics (random walk or coordinated turn), DBSCAN every K_recompute steps with drift
  * test and proportional reassignment, FSPL adjacency, midpoint jamming mask,
  * Laplacian lambda2, 5-term reward, observation. */
 int marl_env_step(const MarlEnvParams *p, const MarlEnvState *s, const MarlStepIO *io, void *stream);

@@ -15,6 +15,7 @@ OBS_DIM = 5
 ASSIGN_NONE = -2
 MAX_N = 256
 MAX_M = 64
+ENEMY_RANDOM_WALK, ENEMY_COORDINATED_TURN = 0, 1
 
 MARL_OK, MARL_EINVAL, MARL_EUNSUPPORTED, MARL_EHIP = 0, -1, -2, -3
 
@@ -26,12 +27,13 @@ class MarlEnvParams(C.Structure):
         ("N", C.c_int32), ("M", C.c_int32),
         ("max_steps", C.c_int32), ("K_recompute", C.c_int32), ("min_samples", C.c_int32),
         ("random_jammer_start", C.c_int32), ("max_reset_attempts", C.c_int32),
-        ("lambda2_rounds", C.c_int32),
+        ("lambda2_rounds", C.c_int32), ("enemy_mode", C.c_int32), ("pad_i32", C.c_int32),
         ("arena_size", C.c_double), ("dt", C.c_double), ("v_max", C.c_double), ("v_enemy", C.c_double),
         ("P_tx_w", C.c_double), ("P_sens_w", C.c_double), ("P_jam_w", C.c_double), ("P_thr_w", C.c_double),
         ("omega", C.c_double * 5),
         ("kappa", C.c_double), ("eps", C.c_double), ("drift_threshold", C.c_double),
         ("spread", C.c_double), ("noise_std", C.c_double), ("min_lambda2_initial", C.c_double),
+        ("omega_max", C.c_double),
         ("comm_d2_max", C.c_double * NUM_BANDS), ("jam_d2_max", C.c_double * NUM_BANDS),
         ("R_jam", C.c_double * NUM_BANDS),
         ("dt_f32", C.c_float), ("v_max_f32", C.c_float), ("v_max_sq_f32", C.c_float), ("pad_f32", C.c_float),
@@ -39,7 +41,7 @@ class MarlEnvParams(C.Structure):
 
 
 _STATE_ARRAYS = [
-    "enemy_x", "enemy_y", "enemy_vx", "enemy_vy", "jam_x", "jam_y", "jam_band", "last_vx", "last_vy",
+    "enemy_x", "enemy_y", "enemy_vx", "enemy_vy", "enemy_omega", "jam_x", "jam_y", "jam_band", "last_vx", "last_vy",
     "step_count", "enemy_band", "lambda2_initial", "labels", "cent_x", "cent_y", "cent_size",
     "n_clusters", "ncent", "prev_x", "prev_y", "prev_n_clusters", "prev_ncent", "assign", "workspace",
     "solve_rows", "solve_np", "solve_slot", "solve_perm", "solve_hist", "solve_partial",
@@ -60,7 +62,7 @@ class MarlStepIO(C.Structure):
 
 class MarlResetIO(C.Structure):
     _fields_ = [
-        ("mask", _pu8), ("enemy_pos", _pd), ("enemy_vel", _pd), ("enemy_band", _pi), ("jam_init", _pd),
+        ("mask", _pu8), ("enemy_pos", _pd), ("enemy_vel", _pd), ("enemy_omega", _pd), ("enemy_band", _pi), ("jam_init", _pd),
         ("jam_band", _pi), ("obs", _pf), ("seed", C.c_uint64), ("episode", C.c_uint64),
         ("env_offset", C.c_uint64),
     ]

@@ -114,6 +114,96 @@ __device__ __forceinline__ void noise_pair(uint64_t seed, uint64_t genv, uint32_
     nx = rad * c; ny = rad * s;
 }
 
+// np.mod(x, a) for a > 0 as numpy computes it for float64 (npy_divmod): C fmod, moved into [0, a).
+__device__ __forceinline__ double numpy_mod(double x, double a) {
+    double r = fmod(x, a);
+    if (r < 0.0) r += a;
+    else if (r == 0.0) r = 0.0;          // -0.0 -> +0.0
+    return r;
+}
+
+// EnemySwarm.step for drone i of env e (enemy_swarm.py:139-155): loads its state, moves it by the
+// random walk (:157-189) or the coordinated-turn model (:191-242), stores it, returns the position.
+__device__ __forceinline__ void enemy_move(const MarlEnvParams& P, const MarlEnvState& S, const MarlStepIO& io,
+                                           int e, int i, int step, double& xo, double& yo) {
+    const size_t o = (size_t)e * P.N + i;
+    const double arena = P.arena_size;
+    const bool ct = P.enemy_mode == MARL_ENEMY_COORDINATED_TURN;
+    double nx, ny;
+    if (io.noise) { nx = io.noise[o * 2]; ny = io.noise[o * 2 + 1]; }
+    else noise_pair(io.seed, io.env_offset + e, (uint32_t)step, (uint32_t)i, ct ? P.noise_std * 0.5 : P.noise_std, nx, ny);
+    double x = S.enemy_x[o], y = S.enemy_y[o], vx = S.enemy_vx[o], vy = S.enemy_vy[o];
+    if (ct) {
+        const double w = S.enemy_omega[o], dt = P.dt;
+        double x1, y1, vx1, vy1;
+        if (fabs(w) < 1e-6) {
+            x1 = x + vx * dt; y1 = y + vy * dt; vx1 = vx; vy1 = vy;
+        } else {
+            double sn, cs;
+            sincos(w * dt, &sn, &cs);
+            x1 = x + (sn / w) * vx - ((1 - cs) / w) * vy;
+            vx1 = cs * vx - sn * vy;
+            y1 = y + ((1 - cs) / w) * vx + (sn / w) * vy;
+            vy1 = sn * vx + cs * vy;
+        }
+        S.enemy_omega[o] = fmin(fmax(w + nx, -P.omega_max), P.omega_max);
+        x = numpy_mod(x1, arena); y = numpy_mod(y1, arena); vx = vx1; vy = vy1;
+    } else {
+        vx = vx + nx; vy = vy + ny;
+        double sp = sqrt(vx * vx + vy * vy);
+        sp = fmax(sp, 1e-6);
+        vx = vx / sp * P.v_enemy;
+        vy = vy / sp * P.v_enemy;
+        x = x + vx * P.dt; y = y + vy * P.dt;
+        if (x < 0.0) { x = -x; vx = -vx; }
+        if (x > arena) { x = 2 * arena - x; vx = -vx; }
+        if (y < 0.0) { y = -y; vy = -vy; }
+        if (y > arena) { y = 2 * arena - y; vy = -vy; }
+        x = fmin(fmax(x, 0.0), arena);
+        y = fmin(fmax(y, 0.0), arena);
+    }
+    S.enemy_x[o] = x; S.enemy_y[o] = y; S.enemy_vx[o] = vx; S.enemy_vy[o] = vy;
+    xo = x; yo = y;
+}
+
+// EnemySwarm.reset for drone i of env e (enemy_swarm.py:244-283 and, for the coordinated turn,
+// :119-137): host-fed values where given, else uniform position in [0.1A, 0.9A], uniform heading,
+// uniform turn rate in [-omega_max/2, omega_max/2] from the counter-based generator.
+__device__ __forceinline__ void enemy_spawn(const MarlEnvParams& P, const MarlEnvState& S, const MarlResetIO& io,
+                                            int e, int i, int attempt, double& xo, double& yo) {
+    const size_t o = (size_t)e * P.N + i;
+    const double arena = P.arena_size;
+    const bool ct = P.enemy_mode == MARL_ENEMY_COORDINATED_TURN;
+    const bool host_init = io.enemy_pos != nullptr;
+    const uint64_t genv = io.env_offset + e;
+    const uint32_t k0 = (uint32_t)io.seed, k1 = (uint32_t)(io.seed >> 32);
+    uint32_t r[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0};
+    if (!host_init || (ct && io.enemy_omega == nullptr)) {
+        philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)i << 8) ^ STREAM_RESET_ENEMY,
+                   (uint32_t)io.episode, (uint32_t)attempt, k0, k1, r);
+        philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)i << 8) ^ STREAM_RESET_ENEMY,
+                   (uint32_t)io.episode, (uint32_t)attempt | 0x80000000u, k0, k1, r2);
+    }
+    double x, y, vx, vy;
+    if (host_init) {
+        x = io.enemy_pos[o * 2]; y = io.enemy_pos[o * 2 + 1];
+        vx = io.enemy_vel[o * 2]; vy = io.enemy_vel[o * 2 + 1];
+    } else {
+        const double margin = arena * 0.1;
+        x = margin + (arena - margin - margin) * u01(r[0], r[1]);
+        y = margin + (arena - margin - margin) * u01(r[2], r[3]);
+        double sn, cs;
+        sincos(kTwoPi * u01(r2[0], r2[1]), &sn, &cs);
+        vx = P.v_enemy * cs; vy = P.v_enemy * sn;
+    }
+    if (ct) {
+        const double lo = -P.omega_max * 0.5, hi = P.omega_max * 0.5;
+        S.enemy_omega[o] = io.enemy_omega ? io.enemy_omega[o] : lo + (hi - lo) * u01(r2[2], r2[3]);
+    }
+    S.enemy_x[o] = x; S.enemy_y[o] = y; S.enemy_vx[o] = vx; S.enemy_vy[o] = vy;
+    xo = x; yo = y;
+}
+
 // ------------------------------------------------------------------ LDS layout of one env
 struct WaveLds {
     double sx[WAVE], sy[WAVE];        // enemy positions
@@ -830,25 +920,10 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
         L.jx[lane] = x; L.jy[lane] = y; L.jb[lane] = band;
         L.asg[lane] = S.assign[(size_t)e * m + lane];
     }
-    // -- enemy random walk (enemy_swarm.py:157-189)
+    // -- enemy dynamics (enemy_swarm.py:139-242)
     if (lane < n) {
-        const size_t o = (size_t)e * n + lane;
-        double nx, ny;
-        if (io.noise) { nx = io.noise[o * 2]; ny = io.noise[o * 2 + 1]; }
-        else noise_pair(io.seed, io.env_offset + e, (uint32_t)step, (uint32_t)lane, P.noise_std, nx, ny);
-        double vx = S.enemy_vx[o] + nx, vy = S.enemy_vy[o] + ny;
-        double sp = sqrt(vx * vx + vy * vy);
-        sp = fmax(sp, 1e-6);
-        vx = vx / sp * P.v_enemy;
-        vy = vy / sp * P.v_enemy;
-        double x = S.enemy_x[o] + vx * P.dt, y = S.enemy_y[o] + vy * P.dt;
-        if (x < 0.0) { x = -x; vx = -vx; }
-        if (x > arena) { x = 2 * arena - x; vx = -vx; }
-        if (y < 0.0) { y = -y; vy = -vy; }
-        if (y > arena) { y = 2 * arena - y; vy = -vy; }
-        x = fmin(fmax(x, 0.0), arena);
-        y = fmin(fmax(y, 0.0), arena);
-        S.enemy_x[o] = x; S.enemy_y[o] = y; S.enemy_vx[o] = vx; S.enemy_vy[o] = vy;
+        double x, y;
+        enemy_move(P, S, io, e, lane, step, x, y);
         L.sx[lane] = x; L.sy[lane] = y;
         L.sxy[lane] = make_double2(x, y);
     }
@@ -1002,27 +1077,9 @@ __global__ __launch_bounds__(WAVE) void env_reset_wave_kernel(MarlEnvParams P, M
     const bool host_init = io.enemy_pos != nullptr;
     const int attempts = host_init ? 1 : (P.max_reset_attempts > 0 ? P.max_reset_attempts : 1);
     for (int attempt = 0; attempt < attempts; ++attempt) {
-        // EnemySwarm.reset (enemy_swarm.py:244-283): uniform positions in [0.1A, 0.9A], uniform headings
         if (lane < n) {
-            const size_t o = (size_t)e * n + lane;
-            double x, y, vx, vy;
-            if (host_init) {
-                x = io.enemy_pos[o * 2]; y = io.enemy_pos[o * 2 + 1];
-                vx = io.enemy_vel[o * 2]; vy = io.enemy_vel[o * 2 + 1];
-            } else {
-                uint32_t r[4], r2[4];
-                philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)lane << 8) ^ STREAM_RESET_ENEMY,
-                           (uint32_t)io.episode, (uint32_t)attempt, k0, k1, r);
-                philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)lane << 8) ^ STREAM_RESET_ENEMY,
-                           (uint32_t)io.episode, (uint32_t)attempt | 0x80000000u, k0, k1, r2);
-                const double margin = arena * 0.1;
-                x = margin + (arena - margin - margin) * u01(r[0], r[1]);
-                y = margin + (arena - margin - margin) * u01(r[2], r[3]);
-                double s, c;
-                sincos(kTwoPi * u01(r2[0], r2[1]), &s, &c);
-                vx = P.v_enemy * c; vy = P.v_enemy * s;
-            }
-            S.enemy_x[o] = x; S.enemy_y[o] = y; S.enemy_vx[o] = vx; S.enemy_vy[o] = vy;
+            double x, y;
+            enemy_spawn(P, S, io, e, lane, attempt, x, y);
             L.sx[lane] = x; L.sy[lane] = y;
         }
         if (io.enemy_band) {
@@ -1210,7 +1267,8 @@ __global__ void fill_noise_kernel(MarlEnvParams P, MarlEnvState S, uint64_t seed
     const int e = blockIdx.x, i = threadIdx.x;
     if (i >= P.N) return;
     double nx, ny;
-    noise_pair(seed, env_offset + e, (uint32_t)(S.step_count[e] + 1), (uint32_t)i, P.noise_std, nx, ny);
+    const double sigma = P.enemy_mode == MARL_ENEMY_COORDINATED_TURN ? P.noise_std * 0.5 : P.noise_std;
+    noise_pair(seed, env_offset + e, (uint32_t)(S.step_count[e] + 1), (uint32_t)i, sigma, nx, ny);
     noise[((size_t)e * P.N + i) * 2] = nx;
     noise[((size_t)e * P.N + i) * 2 + 1] = ny;
 }
@@ -1672,23 +1730,8 @@ __global__ __launch_bounds__(WAVE) void env_step_big_kernel(MarlEnvParams P, Mar
     for (int s = 0; s < S; ++s) {
         const int i = s * WAVE + lane;
         if (i < n) {
-            const size_t o = (size_t)e * n + i;
-            double nx, ny;
-            if (io.noise) { nx = io.noise[o * 2]; ny = io.noise[o * 2 + 1]; }
-            else noise_pair(io.seed, io.env_offset + e, (uint32_t)step, (uint32_t)i, P.noise_std, nx, ny);
-            double vx = St.enemy_vx[o] + nx, vy = St.enemy_vy[o] + ny;
-            double sp = sqrt(vx * vx + vy * vy);
-            sp = fmax(sp, 1e-6);
-            vx = vx / sp * P.v_enemy;
-            vy = vy / sp * P.v_enemy;
-            double x = St.enemy_x[o] + vx * P.dt, y = St.enemy_y[o] + vy * P.dt;
-            if (x < 0.0) { x = -x; vx = -vx; }
-            if (x > arena) { x = 2 * arena - x; vx = -vx; }
-            if (y < 0.0) { y = -y; vy = -vy; }
-            if (y > arena) { y = 2 * arena - y; vy = -vy; }
-            x = fmin(fmax(x, 0.0), arena);
-            y = fmin(fmax(y, 0.0), arena);
-            St.enemy_x[o] = x; St.enemy_y[o] = y; St.enemy_vx[o] = vx; St.enemy_vy[o] = vy;
+            double x, y;
+            enemy_move(P, St, io, e, i, step, x, y);
             L.sx[i] = x; L.sy[i] = y;
         }
     }
@@ -1762,25 +1805,8 @@ __global__ __launch_bounds__(WAVE) void env_reset_big_kernel(MarlEnvParams P, Ma
         for (int s = 0; s < S; ++s) {
             const int i = s * WAVE + lane;
             if (i < n) {
-                const size_t o = (size_t)e * n + i;
-                double x, y, vx, vy;
-                if (host_init) {
-                    x = io.enemy_pos[o * 2]; y = io.enemy_pos[o * 2 + 1];
-                    vx = io.enemy_vel[o * 2]; vy = io.enemy_vel[o * 2 + 1];
-                } else {
-                    uint32_t r[4], r2[4];
-                    philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)i << 8) ^ STREAM_RESET_ENEMY,
-                               (uint32_t)io.episode, (uint32_t)attempt, k0, k1, r);
-                    philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)i << 8) ^ STREAM_RESET_ENEMY,
-                               (uint32_t)io.episode, (uint32_t)attempt | 0x80000000u, k0, k1, r2);
-                    const double margin = arena * 0.1;
-                    x = margin + (arena - margin - margin) * u01(r[0], r[1]);
-                    y = margin + (arena - margin - margin) * u01(r[2], r[3]);
-                    double sn, cs;
-                    sincos(kTwoPi * u01(r2[0], r2[1]), &sn, &cs);
-                    vx = P.v_enemy * cs; vy = P.v_enemy * sn;
-                }
-                St.enemy_x[o] = x; St.enemy_y[o] = y; St.enemy_vx[o] = vx; St.enemy_vy[o] = vy;
+                double x, y;
+                enemy_spawn(P, St, io, e, i, attempt, x, y);
                 L.sx[i] = x; L.sy[i] = y;
             }
         }
@@ -2032,6 +2058,9 @@ int marl_params_init(MarlEnvParams* p) {
     int rc = check_sizes(p);
     if (rc != MARL_OK) return rc;
     if (!(p->arena_size > 0) || !(p->dt > 0) || p->K_recompute < 1 || p->max_steps < 1) return MARL_EINVAL;
+    if (p->enemy_mode != MARL_ENEMY_RANDOM_WALK && p->enemy_mode != MARL_ENEMY_COORDINATED_TURN) return MARL_EINVAL;
+    if (!(p->omega_max > 0)) p->omega_max = 0.5;             // EnemySwarm default (enemy_swarm.py:60)
+    p->pad_i32 = 0;
     for (int b = 0; b < MARL_NUM_BANDS; ++b) {
         const double wl = kSpeedOfLight / band_hz(b);
         p->comm_d2_max[b] = largest_reaching_d2(p->P_tx_w, wl, p->P_sens_w);
@@ -2052,7 +2081,7 @@ size_t marl_state_bytes(const MarlEnvParams* p, int32_t E) {
     if (check_sizes(p) != MARL_OK || E < 1) return 0;
     const size_t n = p->N, m = p->M, ks = n + 1, e = (size_t)E;
     size_t b = 0;
-    b += 4 * align256(e * n * 8);        // enemy x, y, vx, vy
+    b += 5 * align256(e * n * 8);        // enemy x, y, vx, vy, omega
     b += 2 * align256(e * m * 8);        // jam x, y
     b += align256(e * m * 4);            // jam_band
     b += 2 * align256(e * m * 4);        // last_vx, last_vy
@@ -2086,6 +2115,7 @@ int marl_state_bind(MarlEnvState* s, const MarlEnvParams* p, int32_t E, void* ba
     s->E = E; s->pad = 0;
     s->enemy_x = (double*)take(e * n * 8); s->enemy_y = (double*)take(e * n * 8);
     s->enemy_vx = (double*)take(e * n * 8); s->enemy_vy = (double*)take(e * n * 8);
+    s->enemy_omega = (double*)take(e * n * 8);
     s->jam_x = (double*)take(e * m * 8); s->jam_y = (double*)take(e * m * 8);
     s->jam_band = (int32_t*)take(e * m * 4);
     s->last_vx = (float*)take(e * m * 4); s->last_vy = (float*)take(e * m * 4);

@@ -58,6 +58,7 @@ class EnvConfig:
     max_reset_attempts: int = 100
     random_jammer_start: bool = False
     lambda2_rounds: int = 0
+    omega_max: float = 0.5          # EnemySwarm default (enemy_swarm.py:60); JammerEnv does not expose it
 
     @staticmethod
     def fast_preset(N: int = 10, M: int = 4, **kw) -> "EnvConfig":
@@ -68,9 +69,11 @@ class EnvConfig:
         return EnvConfig(**base)
 
     def to_params(self) -> MarlEnvParams:
-        if self.enemy_mode != "random_walk":
-            raise NotImplementedError("only the random_walk enemy model (enemy_swarm.py:157-189) runs on the GPU")
+        if self.enemy_mode not in ("random_walk", "coordinated_turn"):
+            raise ValueError("enemy_mode must be 'random_walk' or 'coordinated_turn' (jammer_env.py:103)")
         p = MarlEnvParams()
+        p.enemy_mode = _lib.ENEMY_COORDINATED_TURN if self.enemy_mode == "coordinated_turn" else _lib.ENEMY_RANDOM_WALK
+        p.omega_max = float(self.omega_max)
         p.N, p.M = int(self.N), int(self.M)
         p.max_steps, p.K_recompute, p.min_samples = int(self.max_steps), int(self.K_recompute), int(self.min_samples)
         p.random_jammer_start = int(bool(self.random_jammer_start))
@@ -91,6 +94,7 @@ class EnvConfig:
 _DT = {"f64": torch.float64, "f32": torch.float32, "i32": torch.int32}
 _STATE_SPEC = {   # name -> (dtype, shape as function of (E, N, M))
     "enemy_x": ("f64", "EN"), "enemy_y": ("f64", "EN"), "enemy_vx": ("f64", "EN"), "enemy_vy": ("f64", "EN"),
+    "enemy_omega": ("f64", "EN"),
     "jam_x": ("f64", "EM"), "jam_y": ("f64", "EM"), "jam_band": ("i32", "EM"),
     "last_vx": ("f32", "EM"), "last_vy": ("f32", "EM"),
     "step_count": ("i32", "E"), "enemy_band": ("i32", "E"), "lambda2_initial": ("f64", "E"),
@@ -162,10 +166,11 @@ class BatchedJammerEnv:
     # -- reset ---------------------------------------------------------------
     def reset(self, seed: Optional[int] = None, mask: Optional[torch.Tensor] = None, *,
               enemy_pos=None, enemy_vel=None, enemy_band=None, jam_init=None, jam_band=None,
-              out_obs: Optional[torch.Tensor] = None):
+              enemy_omega=None, out_obs: Optional[torch.Tensor] = None):
         """JammerEnv.reset for the masked envs (all when mask is None).  The
         keyword tensors override the on-device random draws (enemy_pos/enemy_vel
-        [E,N,2] f64, enemy_band [E] i32, jam_init [E,M,2] f64, jam_band [E,M] i32)."""
+        [E,N,2] f64, enemy_band [E] i32, jam_init [E,M,2] f64, jam_band [E,M] i32; coordinated
+        turn: enemy_omega [E,N] f64)."""
         if seed is not None:
             self.seed = int(seed)
             self._episode = 0
@@ -183,6 +188,7 @@ class BatchedJammerEnv:
             io.mask = dev(mask.to(torch.uint8) if isinstance(mask, torch.Tensor) else np.asarray(mask, np.uint8), torch.uint8)
         io.enemy_pos = dev(enemy_pos, torch.float64)
         io.enemy_vel = dev(enemy_vel, torch.float64)
+        io.enemy_omega = dev(enemy_omega, torch.float64)
         io.enemy_band = dev(enemy_band, torch.int32)
         io.jam_init = dev(jam_init, torch.float64)
         io.jam_band = dev(jam_band, torch.int32)
@@ -391,6 +397,10 @@ class JammerEnv:
             epos = srng._rng.uniform(margin, A - margin, size=(N, 2))     # enemy_swarm.py:266-270
             ang = srng._rng.uniform(0, 2 * np.pi, size=N)
             evel = np.column_stack([self.v_enemy * np.cos(ang), self.v_enemy * np.sin(ang)])
+            eomega = None
+            if self.enemy_mode == "coordinated_turn":                     # enemy_swarm.py:133-137
+                wmax = self.cfg.omega_max
+                eomega = srng._rng.uniform(-wmax * 0.5, wmax * 0.5, size=N)
             self.enemy_band = int(self._rng.randint(0, self.num_bands))   # jammer_env.py:287
             # One attempt of the reference's loop = one fit + lambda2_initial.  The jammer draws
             # are only consumed after the loop ends, so probe with placeholder jammers; the
@@ -409,7 +419,8 @@ class JammerEnv:
         jb = self._rng.randint(0, self.num_bands, size=M).astype(np.int32)  # jammer_env.py:339
         obs_t, _ = self._b.reset(enemy_pos=epos[None], enemy_vel=evel[None],
                                  enemy_band=np.array([self.enemy_band], np.int32),
-                                 jam_init=jinit[None], jam_band=jb[None])
+                                 jam_init=jinit[None], jam_band=jb[None],
+                                 enemy_omega=None if eomega is None else eomega[None])
         torch.cuda.synchronize()
         self.lambda2_initial = float(self._b.views["lambda2_initial"][0].item())
         obs = obs_t[0].cpu().numpy()
@@ -442,7 +453,11 @@ class JammerEnv:
             a[:, 2] = bands
         else:
             a = np.asarray(action, dtype=np.float32)
-        noise = self.enemy_swarm._rng.normal(0, 0.1, size=(self.N, 2))    # enemy_swarm.py:165
+        if self.enemy_mode == "coordinated_turn":                         # enemy_swarm.py:228, one draw per drone
+            noise = np.zeros((self.N, 2))
+            noise[:, 0] = [self.enemy_swarm._rng.normal(0, 0.1 * 0.5) for _ in range(self.N)]
+        else:
+            noise = self.enemy_swarm._rng.normal(0, 0.1, size=(self.N, 2))    # enemy_swarm.py:165
         act_t = torch.from_numpy(np.ascontiguousarray(a[None])).to(self._b.device)
         noise_t = torch.from_numpy(noise[None]).to(self._b.device)
         obs_t, rew_t, _, trunc_t, info_t = self._b.step(act_t, noise_t)

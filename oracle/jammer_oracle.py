@@ -80,6 +80,8 @@ class EnvParams:
     noise_std: float = 0.1         # enemy_swarm.py:61
     drift_threshold: float = 30.0  # jammer_env.py:398
     spread: float = 10.0           # jammer_env.py:335
+    enemy_mode: str = "random_walk"   # jammer_env.py:103, or "coordinated_turn"
+    omega_max: float = 0.5         # enemy_swarm.py:60
 
     @staticmethod
     def fast_preset(N: int = 10, M: int = 4) -> "EnvParams":
@@ -412,6 +414,33 @@ def enemy_step_random_walk(pos, vel, noise, v_enemy, dt, arena_size):
     return np.clip(new, 0, arena_size), vel
 
 
+def enemy_step_coordinated_turn(pos, vel, omega, noise_omega, dt, arena_size, omega_max):
+    """EnemySwarm._step_coordinated_turn (enemy_swarm.py:191-242): per-drone turn
+    with rate omega, then omega += noise_omega (the N scalar normal(0, 0.05)
+    draws, in drone order), clipped; positions wrap modulo the arena.  The
+    scalar loop is kept: np.sin / np.cos of a scalar and of an array element may
+    round differently."""
+    N = pos.shape[0]
+    new_pos, new_vel, new_omega = np.empty_like(pos), np.empty_like(vel), np.empty(N)
+    for i in range(N):
+        x, y = pos[i, 0], pos[i, 1]
+        x_dot, y_dot = vel[i, 0], vel[i, 1]
+        w = omega[i]
+        if abs(w) < 1e-6:
+            nx, ny, nxd, nyd = x + x_dot * dt, y + y_dot * dt, x_dot, y_dot
+        else:
+            sin_wt, cos_wt = np.sin(w * dt), np.cos(w * dt)
+            nx = x + (sin_wt / w) * x_dot - ((1 - cos_wt) / w) * y_dot
+            nxd = cos_wt * x_dot - sin_wt * y_dot
+            ny = y + ((1 - cos_wt) / w) * x_dot + (sin_wt / w) * y_dot
+            nyd = sin_wt * x_dot + cos_wt * y_dot
+        new_pos[i] = (nx, ny)
+        new_vel[i] = (nxd, nyd)
+        new_omega[i] = np.clip(w + noise_omega[i], -omega_max, omega_max)
+    new_pos = np.mod(new_pos, arena_size)
+    return new_pos, new_vel, new_omega
+
+
 # --------------------------------------------------------------------------
 # environment/reward.py, observation.py
 # --------------------------------------------------------------------------
@@ -526,6 +555,7 @@ class EnvState:
     last_velocities: np.ndarray = None
     enemy_pos: np.ndarray = None
     enemy_vel: np.ndarray = None
+    enemy_omega: np.ndarray = None      # coordinated-turn rate per drone (enemy_swarm.py:133)
     clusters: ClusterState = None
     assign: np.ndarray = None
 
@@ -535,6 +565,7 @@ class EnvState:
                         jammer_bands=np.zeros(p.M, dtype=np.int32),
                         last_velocities=np.zeros((p.M, 2)),
                         enemy_pos=np.zeros((p.N, 2)), enemy_vel=np.zeros((p.N, 2)),
+                        enemy_omega=np.zeros(p.N),
                         clusters=ClusterState.empty(p.N),
                         assign=np.full(p.M, ASSIGN_NONE, dtype=np.int64))
 
@@ -554,7 +585,7 @@ def compute_lambda2(p: EnvParams, st: EnvState, disrupted: bool):
 
 
 def env_reset(p: EnvParams, st: EnvState, enemy_pos, enemy_vel, enemy_band,
-              jammer_init, jammer_bands):
+              jammer_init, jammer_bands, enemy_omega=None):
     """Deterministic part of JammerEnv.reset (jammer_env.py:261-354) for ONE
     attempt of its retry loop, given the random draws:
 
@@ -564,12 +595,15 @@ def env_reset(p: EnvParams, st: EnvState, enemy_pos, enemy_vel, enemy_band,
                              (:324-326); else the (M,2) uniform(-10,10) offsets
                              of get_jammer_initial_positions
       jammer_bands           _rng.randint(0, 4, size=M)                (:339)
+      enemy_omega            coordinated turn only: the uniform(-omega_max/2,
+                             omega_max/2, N) draw (enemy_swarm.py:133-137)
 
     The caller repeats with fresh draws while lambda2_initial <
     min_lambda2_initial (:304-308).  Returns (obs, info)."""
     st.step_count = 0
     st.enemy_pos = np.array(enemy_pos, dtype=np.float64)
     st.enemy_vel = np.array(enemy_vel, dtype=np.float64)
+    st.enemy_omega = (np.zeros(p.N) if enemy_omega is None else np.array(enemy_omega, dtype=np.float64))
     st.enemy_band = int(enemy_band)
     f = FREQUENCY_BANDS[st.enemy_band]
     st.R_jam = float(compute_jam_range(db_to_watts(p.P_jammer_dbm),
@@ -602,9 +636,13 @@ def env_step(p: EnvParams, st: EnvState, action, noise, want_avg_power: bool = T
     st.last_velocities = velocity.copy()
     st.jammer_positions = apply_action(st.jammer_positions, velocity, p.dt, p.v_max, p.arena_size)
     st.jammer_bands = clip_bands(bands)
-    st.enemy_pos, st.enemy_vel = enemy_step_random_walk(
-        st.enemy_pos, st.enemy_vel, np.asarray(noise, dtype=np.float64),
-        p.v_enemy, p.dt, p.arena_size)
+    noise = np.asarray(noise, dtype=np.float64)
+    if p.enemy_mode == "coordinated_turn":       # noise[:, 0] = the N turn-rate draws
+        st.enemy_pos, st.enemy_vel, st.enemy_omega = enemy_step_coordinated_turn(
+            st.enemy_pos, st.enemy_vel, st.enemy_omega, noise[:, 0], p.dt, p.arena_size, p.omega_max)
+    else:
+        st.enemy_pos, st.enemy_vel = enemy_step_random_walk(
+            st.enemy_pos, st.enemy_vel, noise, p.v_enemy, p.dt, p.arena_size)
     reassigned = False
     if st.step_count % p.K_recompute == 0:
         cluster_fit(st.clusters, st.enemy_pos, p.eps, p.min_samples, p.arena_size)

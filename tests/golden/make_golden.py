@@ -230,7 +230,10 @@ def record_reset(env, seed, gstate):
     g.set_state(gstate)
     offsets = np.array([g.uniform(-10.0, 10.0, size=2) for _ in range(env.M)])
     ids, cxy, csz, ncent = flatten_clusters(env.N, env.centroids, env.cluster_sizes)
-    return dict(epos=env.enemy_swarm.positions.copy(), evel=env.enemy_swarm.velocities.copy(),
+    extra = {}
+    if env.enemy_swarm.mode == "coordinated_turn":
+        extra["eomega"] = env.enemy_swarm.state[:, 4].copy()
+    return dict(epos=env.enemy_swarm.positions.copy(), evel=env.enemy_swarm.velocities.copy(), **extra,
                 band=np.int32(env.enemy_band), jpos=env.jammer_positions.copy(),
                 jb=env.jammer_bands.copy(), offsets=offsets, lam0=np.float64(env.lambda2_initial),
                 R_jam=np.float64(env.R_jam), labels=env.clusterer.labels.astype(np.int32),
@@ -252,7 +255,8 @@ def make_trajectory(name, N, M, seed, n_steps, policy, **kw):
     resets.append(r)
     rec = {k: [] for k in ("action", "noise", "obs", "reward", "lam", "trunc", "n_clusters",
                            "labels", "epos", "evel", "jpos", "jb", "comps", "avgp", "adj", "jam",
-                           "assign", "cent_ids", "cent_xy", "cent_size", "ncent", "step")}
+                           "assign", "cent_ids", "cent_xy", "cent_size", "ncent", "step", "eomega")}
+    ct = env.enemy_swarm.mode == "coordinated_turn"
     tx, sens = fspl.db_to_watts(env.P_tx_dbm), fspl.db_to_watts(env.P_sens_dbm)
     pj, pt = fspl.db_to_watts(env.P_jammer_dbm), fspl.db_to_watts(env.P_jam_thresh_dbm)
     for t in range(n_steps):
@@ -272,8 +276,13 @@ def make_trajectory(name, N, M, seed, n_steps, policy, **kw):
         st = env.enemy_swarm._rng.get_state()
         rr = np.random.RandomState()
         rr.set_state(st)
-        noise = rr.normal(0, env.enemy_swarm.process_noise_std, size=(N, 2))
+        if ct:      # N scalar draws of normal(0, std/2), one per drone (enemy_swarm.py:228); second column unused
+            noise = np.zeros((N, 2))
+            noise[:, 0] = [rr.normal(0, env.enemy_swarm.process_noise_std * 0.5) for _ in range(N)]
+        else:
+            noise = rr.normal(0, env.enemy_swarm.process_noise_std, size=(N, 2))
         obs, reward, term, trunc, info = env.step(a)
+        rec["eomega"].append(env.enemy_swarm.state[:, 4].copy() if ct else np.zeros(N))
         A = cg.compute_adjacency_matrix(env.enemy_swarm.positions, tx, sens,
                                         env.BANDS[env.enemy_band])
         J = jamming.compute_disrupted_links(env.jammer_positions, env.jammer_bands,
@@ -313,7 +322,8 @@ def make_trajectory(name, N, M, seed, n_steps, policy, **kw):
                v_max=env.v_max, v_enemy=env.v_enemy, P_tx_dbm=env.P_tx_dbm,
                P_sens_dbm=env.P_sens_dbm, P_jammer_dbm=env.P_jammer_dbm,
                P_jam_thresh_dbm=env.P_jam_thresh_dbm, eps=env.eps, min_samples=env.min_samples,
-               K_recompute=env.K_recompute, random_jammer_start=int(env.random_jammer_start))
+               K_recompute=env.K_recompute, random_jammer_start=int(env.random_jammer_start),
+               coordinated_turn=int(ct), omega_max=env.enemy_swarm.omega_max)
     for k, v in cfg.items():
         out[f"cfg_{k}"] = np.float64(v)
     np.savez_compressed(os.path.join(OUT, f"traj_{name}.npz"), **out)
@@ -338,6 +348,13 @@ def make_trajectories():
     big = dict(arena_size=6000.0, max_steps=80, v_max=60.0, v_enemy=40.0, P_jammer_dbm=30.0,
                P_jam_thresh_dbm=-45.0, eps=500.0, K_recompute=5, random_jammer_start=False)
     make_trajectory("n30m6_bigarena", 30, 6, 21, 200, "chase", **big)
+
+
+def make_ct_trajectories():
+    """Second dynamics mode of the enemy swarm (enemy_swarm.py:191-242)."""
+    fast = dict(FAST)
+    make_trajectory("n10m4_ct", 10, 4, 44, 300, "chase", **{**fast, "max_steps": 120, "enemy_mode": "coordinated_turn"})
+    make_trajectory("n50m8_ct", 50, 8, 12, 200, "random", **{**fast, "max_steps": 90, "enemy_mode": "coordinated_turn"})
 
 
 # --------------------------------------------------------------------------
@@ -470,6 +487,10 @@ def make_edges():
 
 
 if __name__ == "__main__":
-    make_stage()
-    make_edges()
-    make_trajectories()
+    if "--ct-only" in sys.argv:       # adds the coordinated-turn files without touching the others
+        make_ct_trajectories()
+    else:
+        make_stage()
+        make_edges()
+        make_trajectories()
+        make_ct_trajectories()

@@ -10,6 +10,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 TRAJ_NAMES = ["n5m2_random", "n10m4_random", "n10m4_chase", "n50m8_random", "n50m8_chase",
               "n200m16_chase", "n20m4_centroid", "n30m6_bigarena"]
+CT_TRAJ_NAMES = ["n10m4_ct", "n50m8_ct"]        # coordinated-turn enemy dynamics
 
 
 def load(name):
@@ -32,7 +33,9 @@ def stage_cases():
 
 def traj_params(z):
     g = lambda k: z[f"cfg_{k}"].item()
-    return orc.EnvParams(M=int(g("M")), N=int(g("N")), arena_size=g("arena_size"),
+    ct = "cfg_coordinated_turn" in z.files and int(g("coordinated_turn")) == 1
+    extra = dict(enemy_mode="coordinated_turn", omega_max=g("omega_max")) if ct else {}
+    return orc.EnvParams(**extra, M=int(g("M")), N=int(g("N")), arena_size=g("arena_size"),
                          max_steps=int(g("max_steps")), dt=g("dt"), v_max=g("v_max"),
                          v_enemy=g("v_enemy"), P_tx_dbm=g("P_tx_dbm"), P_sens_dbm=g("P_sens_dbm"),
                          P_jammer_dbm=g("P_jammer_dbm"), P_jam_thresh_dbm=g("P_jam_thresh_dbm"),

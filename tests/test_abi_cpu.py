@@ -26,11 +26,11 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_sizes_match_header_layout():
-    # 8 int32 + 19 double + 12 double + 4 float
-    assert C.sizeof(_lib.MarlEnvParams) == 8 * 4 + 31 * 8 + 4 * 4
-    assert C.sizeof(_lib.MarlEnvState) == 8 + 30 * 8
+    # 10 int32 + 20 double + 12 double + 4 float
+    assert C.sizeof(_lib.MarlEnvParams) == 10 * 4 + 32 * 8 + 4 * 4
+    assert C.sizeof(_lib.MarlEnvState) == 8 + 31 * 8
     assert C.sizeof(_lib.MarlStepIO) == 12 * 8
-    assert C.sizeof(_lib.MarlResetIO) == 10 * 8
+    assert C.sizeof(_lib.MarlResetIO) == 11 * 8
 
 
 @pytest.mark.parametrize("cfg", [EnvConfig.fast_preset(), EnvConfig(),

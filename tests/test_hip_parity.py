@@ -26,7 +26,7 @@ def cfg_from(p: orc.EnvParams, **kw) -> EnvConfig:
                      v_enemy=p.v_enemy, P_tx_dbm=p.P_tx_dbm, P_sens_dbm=p.P_sens_dbm,
                      P_jammer_dbm=p.P_jammer_dbm, P_jam_thresh_dbm=p.P_jam_thresh_dbm, eps=p.eps,
                      min_samples=p.min_samples, K_recompute=p.K_recompute,
-                     random_jammer_start=p.random_jammer_start, **kw)
+                     random_jammer_start=p.random_jammer_start, enemy_mode=p.enemy_mode, omega_max=p.omega_max, **kw)
 
 
 def dev(a, dtype):
@@ -237,11 +237,21 @@ def test_gae_matches_reference_buffer():
 
 
 # ---------------------------------------------------------------- whole trajectories of the reference env
-@pytest.mark.parametrize("name", gu.TRAJ_NAMES)
+@pytest.mark.parametrize("name", gu.TRAJ_NAMES + gu.CT_TRAJ_NAMES)
 def test_trajectory_matches_reference(name):
+    """Random walk: the whole trajectory is bit-identical to the reference's.  Coordinated turn: the
+    model calls sin / cos, which the device library and numpy round differently in the last bit, so
+    positions, velocities, turn rates and centroids are compared to 1e-12 relative (+1e-10 absolute)
+    there; the integer and boolean outputs stay exact."""
     z = gu.load(f"traj_{name}.npz")
     p = gu.traj_params(z)
     resets = gu.traj_resets(z)
+    ct = p.enemy_mode == "coordinated_turn"
+
+    def same(a, b):
+        if ct:
+            return np.allclose(a, b, rtol=1e-12, atol=1e-10)
+        return np.array_equal(a, b)
     E = 3      # the same trajectory in every env of a small batch
     env = BatchedJammerEnv(E, cfg_from(p), auto_reset=False, track_avg_power=True, debug_bits=True)
     rep = lambda a: np.repeat(np.asarray(a)[None], E, 0)
@@ -249,7 +259,8 @@ def test_trajectory_matches_reference(name):
     def do_reset(r):
         init = r["jpos"] if p.random_jammer_start else r["offsets"]
         obs, info = env.reset(enemy_pos=rep(r["epos"]), enemy_vel=rep(r["evel"]),
-                              enemy_band=rep(np.int32(r["band"])), jam_init=rep(init), jam_band=rep(r["jb"]))
+                              enemy_band=rep(np.int32(r["band"])), jam_init=rep(init), jam_band=rep(r["jb"]),
+                              enemy_omega=rep(r["eomega"]) if ct else None)
         torch.cuda.synchronize()
         v = env.views
         for e in range(E):
@@ -273,9 +284,11 @@ def test_trajectory_matches_reference(name):
         v = env.views
         for e in (0, E - 1):
             assert int(v["step_count"][e]) == int(z["step"][t])
-            assert np.array_equal(v["enemy_x"][e].cpu().numpy(), z["epos"][t][:, 0]), t
-            assert np.array_equal(v["enemy_y"][e].cpu().numpy(), z["epos"][t][:, 1]), t
-            assert np.array_equal(v["enemy_vx"][e].cpu().numpy(), z["evel"][t][:, 0]), t
+            assert same(v["enemy_x"][e].cpu().numpy(), z["epos"][t][:, 0]), t
+            assert same(v["enemy_y"][e].cpu().numpy(), z["epos"][t][:, 1]), t
+            assert same(v["enemy_vx"][e].cpu().numpy(), z["evel"][t][:, 0]), t
+            if ct:
+                assert same(v["enemy_omega"][e].cpu().numpy(), z["eomega"][t]), t
             assert np.array_equal(v["jam_x"][e].cpu().numpy(), z["jpos"][t][:, 0]), t
             assert np.array_equal(v["jam_band"][e].cpu().numpy(), z["jb"][t])
             assert np.array_equal(bits_np(env.adj_bits[e]), z["adj"][t]), t
@@ -283,7 +296,7 @@ def test_trajectory_matches_reference(name):
             assert np.array_equal(v["labels"][e].cpu().numpy().astype(np.int16), z["labels"][t]), t
             nc = int(z["ncent"][t])
             assert int(v["ncent"][e]) == nc and int(v["n_clusters"][e]) == int(z["n_clusters"][t])
-            assert np.array_equal(v["cent_x"][e, :nc].cpu().numpy(), z["cent_xy"][t][:nc, 0]), t
+            assert same(v["cent_x"][e, :nc].cpu().numpy(), z["cent_xy"][t][:nc, 0]), t
             assert np.array_equal(v["cent_size"][e, :nc].cpu().numpy(), z["cent_size"][t][:nc])
             assert np.array_equal(v["assign"][e].cpu().numpy(), z["assign"][t]), t
             assert lam_ok(float(info["lambda2_current"][e]), float(z["lam"][t])), t
@@ -492,3 +505,101 @@ def test_facade_centroid_start_and_api_contract():
     for _ in range(4):
         obs, r, term, trunc, info = env.step(np.zeros((2, 3), dtype=np.float32))
     assert trunc and not term and info["step"] == 5
+
+
+# ---------------------------------------------------------------- coordinated-turn enemy model
+@pytest.mark.parametrize("N,M,E", [(12, 3, 16), (50, 8, 8), (130, 16, 3)])
+def test_coordinated_turn_steps_match_oracle(N, M, E):
+    """enemy_swarm.py:191-242 against the oracle from host-fed draws, with the corner cases planted:
+    turn rates of exactly 0 and below 1e-6 (linear branch), at +-omega_max (clip), drones about to
+    leave the arena on every side (np.mod wrap).  Tolerance as in the trajectory test: sin / cos."""
+    rng = np.random.RandomState(77 + N)
+    p = orc.EnvParams.fast_preset(N=N, M=M)
+    p.enemy_mode, p.max_steps = "coordinated_turn", 1000
+    A = p.arena_size
+    env = BatchedJammerEnv(E, cfg_from(p), auto_reset=False, debug_bits=True)
+    epos = rng.uniform(0.1 * A, 0.9 * A, size=(E, N, 2))
+    ang = rng.uniform(0, 2 * np.pi, size=(E, N))
+    evel = np.stack([2 * np.cos(ang), 2 * np.sin(ang)], axis=2)
+    eom = rng.uniform(-0.25, 0.25, size=(E, N))
+    eom[:, 0], eom[:, 1], eom[:, 2], eom[:, 3] = 0.0, 5e-7, 0.5, -0.5
+    epos[:, 4] = (0.3, 100.0); evel[:, 4] = (-2.0, 0.0)          # leaves through x = 0
+    epos[:, 5] = (A - 0.3, 50.0); evel[:, 5] = (2.0, 0.0)        # through x = A
+    epos[:, 6] = (20.0, 0.2); evel[:, 6] = (0.0, -2.0)           # through y = 0
+    epos[:, 7] = (30.0, A - 0.2); evel[:, 7] = (0.0, 2.0)        # through y = A
+    eom[:, 4:8] = 0.0
+    eband = rng.randint(0, 4, size=E).astype(np.int32)
+    jinit = rng.uniform(0.1 * A, 0.9 * A, size=(E, M, 2))
+    jb = rng.randint(0, 4, size=(E, M)).astype(np.int32)
+    env.reset(enemy_pos=epos, enemy_vel=evel, enemy_band=eband, jam_init=jinit, jam_band=jb, enemy_omega=eom)
+    states = [orc.EnvState.empty(p) for _ in range(E)]
+    for e in range(E):
+        orc.env_reset(p, states[e], epos[e], evel[e], eband[e], jinit[e], jb[e], eom[e])
+    close = lambda a, b: np.allclose(a, b, rtol=1e-12, atol=1e-10)
+    for t in range(12):
+        act = rng.uniform(-6, 6, size=(E, M, 3)).astype(np.float32)
+        act[:, :, 2] = rng.uniform(-1, 5, size=(E, M))
+        noise = np.zeros((E, N, 2))
+        noise[:, :, 0] = rng.normal(0, 0.05, size=(E, N))
+        obs, rew, _, trunc, info = env.step(torch.from_numpy(act).cuda(), torch.from_numpy(noise).cuda())
+        torch.cuda.synchronize()
+        v = env.views
+        for e in range(E):
+            o, r, _, _, inf = orc.env_step(p, states[e], act[e], noise[e], want_avg_power=False)
+            st = states[e]
+            x = v["enemy_x"][e].cpu().numpy()
+            assert close(x, st.enemy_pos[:, 0]) and close(v["enemy_y"][e].cpu().numpy(), st.enemy_pos[:, 1]), (t, e)
+            assert close(v["enemy_vx"][e].cpu().numpy(), st.enemy_vel[:, 0])
+            assert close(v["enemy_omega"][e].cpu().numpy(), st.enemy_omega)
+            assert x.min() >= 0.0 and x.max() <= A
+            assert np.array_equal(bits_np(env.adj_bits[e]), orc.pack_rows(inf["adjacency"] | inf["jammed"]))
+            assert np.array_equal(bits_np(env.jam_bits[e]), orc.pack_rows(inf["jammed"]))
+            assert np.array_equal(v["labels"][e].cpu().numpy(), st.clusters.labels)
+            assert lam_ok(float(info["lambda2_current"][e]), inf["lambda2_current"])
+            assert abs(float(rew[e]) - r) <= 1e-5 * max(1.0, abs(r))
+            np.testing.assert_allclose(obs[e].cpu().numpy(), o, rtol=1e-5, atol=1e-6)
+    # the wrapped drones really crossed
+    assert float(v["enemy_x"][0, 4]) > A / 2 and float(v["enemy_x"][0, 5]) < A / 2
+
+
+def test_coordinated_turn_generator_mode():
+    """Device-drawn turn rates lie in [-omega_max/2, omega_max/2] (enemy_swarm.py:133-137); a step with
+    the device generator equals a step fed with marl_fill_noise's output; the noise is N(0, 0.05)."""
+    cfg = EnvConfig.fast_preset(N=50, M=8, enemy_mode="coordinated_turn")
+    a = BatchedJammerEnv(64, cfg, seed=5, auto_reset=False)
+    b = BatchedJammerEnv(64, cfg, seed=5, auto_reset=False)
+    a.reset(); b.reset()
+    w = a.views["enemy_omega"]
+    assert float(w.min()) >= -0.25 and float(w.max()) <= 0.25 and float(w.std()) > 0.1
+    assert torch.equal(w, b.views["enemy_omega"])
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for t in range(8):
+        act = (torch.rand(64, 8, 3, device="cuda", generator=g) - 0.5) * 10
+        noise = b.fill_noise()
+        oa, ra, _, _, _ = a.step(act)
+        ob, rb, _, _, _ = b.step(act, noise)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb)
+        assert torch.equal(a.views["enemy_x"], b.views["enemy_x"])
+        assert torch.equal(a.views["enemy_omega"], b.views["enemy_omega"])
+    assert abs(float(noise[:, :, 0].std()) - 0.05) < 3e-3
+    assert float(a.views["enemy_omega"].abs().max()) <= 0.5
+
+
+def test_facade_coordinated_turn_reproduces_reference_from_seed():
+    """JammerEnv(enemy_mode='coordinated_turn', seed=s): the facade consumes numpy's RandomState as the
+    reference does (one extra uniform(N) for the turn rates at reset, N scalar normals per step)."""
+    z = gu.load("traj_n10m4_ct.npz")
+    p = gu.traj_params(z)
+    np.random.seed(44 + 1000)
+    env = JammerEnv(M=p.M, N=p.N, seed=44, arena_size=p.arena_size, max_steps=p.max_steps,
+                    P_jammer_dbm=p.P_jammer_dbm, P_jam_thresh_dbm=p.P_jam_thresh_dbm, eps=p.eps,
+                    random_jammer_start=p.random_jammer_start, enemy_mode="coordinated_turn")
+    obs, info = env.reset(seed=44)
+    r0 = gu.traj_resets(z)[0]
+    assert lam_ok(info["lambda2_initial"], float(r0["lam0"]))
+    np.testing.assert_allclose(obs, r0["obs"], rtol=1e-5, atol=1e-6)
+    for t in range(40):
+        obs, rew, term, trunc, info = env.step(z["action"][t])
+        np.testing.assert_allclose(info["enemy_positions"], z["epos"][t], rtol=1e-12, atol=1e-10)
+        assert lam_ok(info["lambda2_current"], float(z["lam"][t])), t
+        assert abs(rew - float(z["reward"][t])) <= 1e-5 * max(1.0, abs(float(z["reward"][t])))

@@ -190,7 +190,7 @@ def test_reward_and_obs_sentinels():
 
 
 # ---------------------------------------------------------------- trajectories
-@pytest.mark.parametrize("name", gu.TRAJ_NAMES)
+@pytest.mark.parametrize("name", gu.TRAJ_NAMES + gu.CT_TRAJ_NAMES)
 def test_trajectory(name):
     z = gu.load(f"traj_{name}.npz")
     p = gu.traj_params(z)
@@ -200,7 +200,7 @@ def test_trajectory(name):
 
     def do_reset(r):
         init = r["jpos"] if p.random_jammer_start else r["offsets"]
-        obs, info = orc.env_reset(p, st, r["epos"], r["evel"], int(r["band"]), init, r["jb"])
+        obs, info = orc.env_reset(p, st, r["epos"], r["evel"], int(r["band"]), init, r["jb"], r.get("eomega"))
         assert np.array_equal(st.jammer_positions, r["jpos"])
         assert info["lambda2_initial"] == float(r["lam0"])
         assert st.R_jam == float(r["R_jam"])
@@ -217,6 +217,8 @@ def test_trajectory(name):
         assert info["step"] == int(z["step"][t])
         assert np.array_equal(st.enemy_pos, z["epos"][t]), t
         assert np.array_equal(st.enemy_vel, z["evel"][t]), t
+        if p.enemy_mode == "coordinated_turn":
+            assert np.array_equal(st.enemy_omega, z["eomega"][t]), t
         assert np.array_equal(st.jammer_positions, z["jpos"][t]), t
         assert np.array_equal(st.jammer_bands, z["jb"][t])
         assert np.array_equal(orc.pack_rows(info["adjacency"] | info["jammed"]), z["adj"][t])
