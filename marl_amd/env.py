@@ -101,6 +101,7 @@ _STATE_SPEC = {   # name -> (dtype, shape as function of (E, N, M))
     "labels": ("i32", "EN"), "cent_x": ("f64", "EK"), "cent_y": ("f64", "EK"), "cent_size": ("i32", "EK"),
     "n_clusters": ("i32", "E"), "ncent": ("i32", "E"), "prev_x": ("f64", "EK"), "prev_y": ("f64", "EK"),
     "prev_n_clusters": ("i32", "E"), "prev_ncent": ("i32", "E"), "assign": ("i32", "EM"),
+    "solve_np": ("i32", "E"), "solve_hist": ("i32", "H"),       # front -> solve hand-over (N <= 64 only)
 }
 
 
@@ -145,7 +146,10 @@ class BatchedJammerEnv:
                                                 C.c_void_p(base)), "marl_state_bind")
             dims = {"E": (self.E,), "EN": (self.E, self.N), "EM": (self.E, self.M), "EK": (self.E, self.N + 1)}
             self.views: Dict[str, torch.Tensor] = {}
+            dims["H"] = (128,)
             for name, (dt, shp) in _STATE_SPEC.items():
+                if getattr(self.state, name) is None:
+                    continue
                 off = getattr(self.state, name) - self._buf.data_ptr()
                 shape = dims[shp]
                 dtype = _DT[dt]

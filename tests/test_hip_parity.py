@@ -603,3 +603,62 @@ def test_facade_coordinated_turn_reproduces_reference_from_seed():
         np.testing.assert_allclose(info["enemy_positions"], z["epos"][t], rtol=1e-12, atol=1e-10)
         assert lam_ok(info["lambda2_current"], float(z["lam"][t])), t
         assert abs(rew - float(z["reward"][t])) <= 1e-5 * max(1.0, abs(float(z["reward"][t])))
+
+
+# ---------------------------------------------------------------- full benchmark size: properties
+def _unpack_bits(bits, N):
+    """[E,N,W] int32 -> bool [E,N,N] on the device."""
+    w = bits.to(torch.int64) & 0xFFFFFFFF
+    j = torch.arange(N, device=bits.device)
+    return ((w[:, :, j // 32] >> (j % 32)) & 1).bool()
+
+
+@pytest.mark.parametrize("mode", ["random_walk", "coordinated_turn"])
+def test_full_size_step_properties(mode):
+    """8 192 envs x (N=50, M=8), the benchmark's shard, device generator: size-independent properties of
+    every step output, and lambda2 against a batched float64 eigvalsh of the Laplacians rebuilt from the
+    kernel's own adjacency / mask bits."""
+    E, N, M = 8192, 50, 8
+    cfg = EnvConfig.fast_preset(N=N, M=M, enemy_mode=mode, max_steps=6)
+    env = BatchedJammerEnv(E, cfg, seed=11, auto_reset=False, debug_bits=True)
+    twin = BatchedJammerEnv(E, cfg, seed=11, auto_reset=False)
+    env.reset(); twin.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    eye = torch.eye(N, dtype=torch.bool, device="cuda")
+    seen_complete = seen_disconnected = seen_solved = 0
+    for t in range(6):
+        act = (torch.rand(E, M, 3, device="cuda", generator=g) - 0.5) * 12
+        act[:, :, 2] = torch.randint(0, 4, (E, M), device="cuda", generator=g).float()
+        obs, rew, term, trunc, info = env.step(act)
+        obs2, rew2, _, _, info2 = twin.step(act)
+        lam = info["lambda2_current"]
+        # same seed, same inputs -> same outputs, whatever order the solves ran in
+        assert torch.equal(obs, obs2) and torch.equal(rew, rew2) and torch.equal(lam, info2["lambda2_current"])
+        adj, jam = _unpack_bits(env.adj_bits, N), _unpack_bits(env.jam_bits, N)
+        assert torch.equal(adj, adj.transpose(1, 2)) and torch.equal(jam, jam.transpose(1, 2))
+        assert not (adj & eye).any() and not (jam & eye).any()
+        eff = (adj & ~jam).double()
+        deg = eff.sum(2)
+        L = torch.diag_embed(deg) - eff
+        ref = torch.linalg.eigvalsh(L)[:, 1]
+        assert float(((lam - ref).abs() / ref.abs().clamp(min=1.0)).max()) < 1e-9
+        assert float(lam.min()) >= 0.0 and float(lam.max()) <= N
+        assert bool((lam <= deg.min(1).values * N / (N - 1) + 1e-9).all())        # Fiedler's bound
+        complete = deg.min(1).values == N - 1
+        assert bool((lam[complete] == N).all())
+        reach = (eff + eye.double())
+        for _ in range(6):
+            reach = (reach @ reach).clamp(max=1.0)
+        connected = reach.min(2).values.min(1).values > 0
+        assert bool((lam[~connected] == 0.0).all()) and bool((lam[connected] > 1e-9).all())
+        seen_complete += int(complete.sum()); seen_disconnected += int((~connected).sum())
+        seen_solved += int((connected & ~complete).sum())
+        assert float(rew.min()) >= -10.0 and float(rew.max()) <= 10.0
+        assert float(obs.min()) >= 0.0 and float(obs.max()) <= 1.0
+        assert bool((trunc == (t == 5)).all()) and not term.any()
+        x, y = env.views["enemy_x"], env.views["enemy_y"]
+        assert float(x.min()) >= 0 and float(x.max()) <= 200 and float(y.min()) >= 0 and float(y.max()) <= 200
+        sp = (env.views["enemy_vx"] ** 2 + env.views["enemy_vy"] ** 2).sqrt()
+        assert float((sp - 2.0).abs().max()) < 1e-9                               # both models keep the speed
+        assert int(env.views["solve_hist"][:65].abs().sum()) == 0                 # hand-over histogram left clean
+    assert seen_solved > 0 and seen_complete > 0                                  # all three lambda2 routes ran
