@@ -108,7 +108,8 @@ typedef struct MarlEnvState {
     int32_t *solve_np;         /* [E] vertices in the eigenproblem, 0 = lambda2 already final */
     int32_t *solve_slot;       /* [E] rank of the env among those with the same solve_np */
     int32_t *solve_perm;       /* [E] env indices, largest eigenproblem first */
-    int32_t *solve_hist;       /* [128] envs per solve_np (bins 0..64); [65] = envs to solve in this step */
+    int32_t *solve_hist;       /* [1344] 16 histograms of solve_np (80 words apart, envs spread by index to keep the
+                                  atomics uncontended); [1280] = envs to solve in this step */
     double *solve_partial;     /* [E][4] reward terms 2..5 awaiting the lambda2 term */
 } MarlEnvState;
 

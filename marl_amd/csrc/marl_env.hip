@@ -107,10 +107,12 @@ __device__ __forceinline__ void noise_pair(uint64_t seed, uint64_t genv, uint32_
     uint32_t r[4];
     philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ (i << 8) ^ STREAM_NOISE, step, i,
                (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    const double u1 = u01(r[0], r[1]), u2 = u01(r[2], r[3]);
-    const double rad = sqrt(-2.0 * log(u1)) * sigma;
-    double s, c;
-    sincos(kTwoPi * u2, &s, &c);
+    // Box-Muller with the hardware's single-precision log2 / sin / cos (v_log_f32, v_sin_f32 and
+    // v_cos_f32 take their argument in revolutions): these draws have no counterpart in the reference,
+    // only their distribution matters, and seven good digits of it are plenty.
+    const float u1 = (float)u01(r[0], r[1]), u2 = (float)u01(r[2], r[3]);      // u1 >= 2^-54 > 0
+    const double rad = (double)__builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * sigma;   // -2 ln 2 * log2
+    const double s = (double)__builtin_amdgcn_sinf(u2), c = (double)__builtin_amdgcn_cosf(u2);
     nx = rad * c; ny = rad * s;
 }
 
@@ -294,8 +296,14 @@ __device__ __forceinline__ void pair_pass(const WaveLds& L, int n, int lane, dou
 // Adjacency row (communication_graph.py:41-105) and disrupted-links row (jamming.py:151-247) of
 // enemy `lane`: the first four matching jammers share the adjacency pass, further ones (rare) take
 // extra passes of four, padded with jammers that reach nothing.
+//
+// Inside a step every enemy lies in [0, A]^2 (clip of the random walk, modulo of the coordinated turn),
+// so when the communication range exceeds the arena's diagonal the adjacency is the complete graph
+// and its test is skipped (`arena` > 0 enables the shortcut; the presets with A = 200 m all take it:
+// the range at 20 dBm / -90 dBm is 1.3 km at 5.8 GHz).
 __device__ __forceinline__ void pair_rows(const WaveLds& L, int n, int m, int lane, int eband, double d2_comm,
-                                          double d2_jam, uint64_t& adj, uint64_t& jam) {
+                                          double d2_jam, double arena, uint64_t& adj, uint64_t& jam) {
+    const bool all_linked = arena > 0.0 && d2_comm >= 2.000001 * arena * arena;
     uint64_t mm = ballot64(lane < m && L.jb[lane & (WAVE - 1)] == eband);
     const int cnt = __popcll(mm);
     const double thr4 = 4.0 * d2_jam;
@@ -313,12 +321,24 @@ __device__ __forceinline__ void pair_rows(const WaveLds& L, int n, int m, int la
     };
     adj = 0; jam = 0;
     next_four();
-    switch (cnt < 4 ? cnt : 4) {
-        case 0: pair_pass<0, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
-        case 1: pair_pass<1, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
-        case 2: pair_pass<2, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
-        case 3: pair_pass<3, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
-        default: pair_pass<4, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+    if (all_linked) {
+        const uint64_t active = (n >= 64) ? ~0ull : ((1ull << n) - 1);
+        adj = (lane < n) ? (active & ~(1ull << lane)) : 0ull;
+        switch (cnt < 4 ? cnt : 4) {
+            case 0: break;
+            case 1: pair_pass<1, false>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+            case 2: pair_pass<2, false>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+            case 3: pair_pass<3, false>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+            default: pair_pass<4, false>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+        }
+    } else {
+        switch (cnt < 4 ? cnt : 4) {
+            case 0: pair_pass<0, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+            case 1: pair_pass<1, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+            case 2: pair_pass<2, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+            case 3: pair_pass<3, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+            default: pair_pass<4, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+        }
     }
     while (mm) {
         next_four();
@@ -789,22 +809,29 @@ __device__ __forceinline__ RewardOut reward_obs_wave(const MarlEnvParams& P, int
     const double xj = L.jx[lane & (WAVE - 1)], yj = L.jy[lane & (WAVE - 1)];
     const double Rjam = P.R_jam[eband];
     // nearest centroid over every dict entry, first minimum wins
-    double best = INFINITY;
+    // (compared as squared distances, one square root at the end; the outputs of this function are
+    // float32 observations and a reward with a 1e-5 tolerance, so the square roots here are the
+    // two-Newton-step ones)
+    double best2 = INFINITY;
     int bslot = 0;
     for (int s = 0; s < ncent; ++s) {
         const double dx = xj - L.cx[s], dy = yj - L.cy[s];
-        const double d = sqrt(dx * dx + dy * dy);
-        if (d < best) { best = d; bslot = s; }
+        const double d2 = dx * dx + dy * dy;
+        if (d2 < best2) { best2 = d2; bslot = s; }
     }
+    const double best = (best2 > 0.0 && best2 < INFINITY) ? fast_sqrt(best2) : best2;
     // pairwise jammer distances: overlap count (pairs k > j) and mean distance to the others
-    const double thr = 2 * Rjam;
+    const double thr = 2 * Rjam, thr2 = thr * thr;
     int ov = 0;
     double dsum = 0.0;
     for (int k = 0; k < m; ++k) {
         const double dx = xj - L.jx[k], dy = yj - L.jy[k];
-        const double d = sqrt(dx * dx + dy * dy);
+        const double d2 = dx * dx + dy * dy;
+        const double d = d2 > 0.0 ? fast_sqrt(d2) : 0.0;
         if (k != lane) dsum = dsum + d;
-        if (k > lane && d < thr) ++ov;
+        // overlap test of reward.py:300-304 on the exactly rounded distance when it is a near tie
+        const bool close = (fabs(d2 - thr2) <= 1e-12 * thr2) ? (sqrt(d2) < thr) : (d2 < thr2);
+        if (k > lane && close) ++ov;
     }
     const int ovl = wave_sum(act ? ov : 0);
     const double r5 = (m > 1) ? (double)ovl / ((double)(m * (m - 1)) / 2) : 0.0;
@@ -819,7 +846,8 @@ __device__ __forceinline__ RewardOut reward_obs_wave(const MarlEnvParams& P, int
         if (c >= 0 && c < num) slot = c;
         else if (c == -1 && ncent > num) slot = num;
         const double dx = xj - L.cx[slot], dy = yj - L.cy[slot];
-        prox = exp(-P.kappa * sqrt(dx * dx + dy * dy));
+        const double d2 = dx * dx + dy * dy;
+        prox = exp(-P.kappa * (d2 > 0.0 ? fast_sqrt(d2) : 0.0));
     }
     const double r3 = wave_sum(prox) / (double)m;
     // term 4 (reward.py:262-280), float32 like the reference's float32 action path
@@ -886,7 +914,10 @@ __device__ __forceinline__ WaveLds& carve(unsigned char* smem) { return *reinter
 // envs in index order, leaves most SIMDs idle while the last long solves finish.  Split like this
 // the cheap, uniform part runs at the occupancy its small register footprint allows, and the
 // solves are started longest first.
-enum { SOLVE_HIST_TOTAL = 65, SOLVE_HIST_WORDS = 128 };
+// solve_hist: SOLVE_HIST_SUBS histograms over n' (the envs spread over them by index, which keeps the
+// atomic traffic per counter low), SOLVE_HIST_STRIDE words apart, then the number of pending solves.
+enum { SOLVE_HIST_SUBS = 16, SOLVE_HIST_STRIDE = 80, SOLVE_HIST_TOTAL = SOLVE_HIST_SUBS * SOLVE_HIST_STRIDE,
+       SOLVE_HIST_WORDS = SOLVE_HIST_TOTAL + 64 };
 
 // Front half: everything of JammerEnv.step but the eigen-solve.
 __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
@@ -965,7 +996,11 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
     }
     // -- lambda2 of the jammed graph (jammer_env.py:464-508)
     uint64_t adj, jam;
-    pair_rows(L, n, m, lane, eband, P.comm_d2_max[eband], P.jam_d2_max[eband], adj, jam);
+#ifdef MARL_EXP_NO_PAIR
+    adj = (lane < n) ? (((1ull << n) - 1) & ~(1ull << lane)) : 0; jam = (lane < n) ? (0x5555555555ull >> lane) & adj & ((1ull << n) - 1) : 0;
+#else
+    pair_rows(L, n, m, lane, eband, P.comm_d2_max[eband], P.jam_d2_max[eband], arena, adj, jam);
+#endif
     store_bits(io.adj_bits, e, n, lane, adj);
     store_bits(io.jam_bits, e, n, lane, jam);
     double lam;
@@ -995,7 +1030,11 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
             io.reward[e] = (float)rw.total;
             if (io.lambda2) io.lambda2[e] = lam;
         } else {
-            S.solve_slot[e] = atomicAdd(&S.solve_hist[np], 1);
+#ifdef MARL_EXP_NO_ATOMIC
+            S.solve_slot[e] = e;
+#else
+            S.solve_slot[e] = atomicAdd(&S.solve_hist[(e & (SOLVE_HIST_SUBS - 1)) * SOLVE_HIST_STRIDE + np], 1);
+#endif
             double* part = S.solve_partial + (size_t)e * 4;
             part[0] = rw.d2; part[1] = rw.d3; part[2] = (double)rw.r3; part[3] = rw.d5;
         }
@@ -1005,24 +1044,35 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
 // Order: env indices of the pending solves into solve_perm, largest matrix first (a counting sort
 // over the histogram the front kernel built).  Every block derives the bin offsets itself.
 __global__ __launch_bounds__(1024) void solve_order_kernel(int E, MarlEnvState S) {
-    __shared__ int start[WAVE + 1];
+    __shared__ int start[SOLVE_HIST_SUBS][WAVE + 1];
     if (threadIdx.x < WAVE) {                        // lane i stands for bin 64 - i: largest matrices first
         const int bin = WAVE - (int)threadIdx.x;
-        const int own = S.solve_hist[bin];
+        int cnt[SOLVE_HIST_SUBS];
+        int own = 0;
+#pragma unroll
+        for (int k = 0; k < SOLVE_HIST_SUBS; ++k) {
+            cnt[k] = S.solve_hist[k * SOLVE_HIST_STRIDE + bin];
+            own += cnt[k];
+        }
         int incl = own;
 #pragma unroll
         for (int o = 1; o < WAVE; o <<= 1) {
             const int up = __shfl_up(incl, o);
             if ((int)threadIdx.x >= o) incl += up;
         }
-        start[bin] = incl - own;
+        int at = incl - own;
+#pragma unroll
+        for (int k = 0; k < SOLVE_HIST_SUBS; ++k) {
+            start[k][bin] = at;
+            at += cnt[k];
+        }
         if (blockIdx.x == 0 && threadIdx.x == WAVE - 1) S.solve_hist[SOLVE_HIST_TOTAL] = incl;
     }
     __syncthreads();
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < E) {
         const int np = S.solve_np[e];
-        if (np > 0) S.solve_perm[start[np] + S.solve_slot[e]] = e;
+        if (np > 0) S.solve_perm[start[e & (SOLVE_HIST_SUBS - 1)][np] + S.solve_slot[e]] = e;
     }
 }
 
@@ -1040,10 +1090,8 @@ __global__ __launch_bounds__(WAVE) void env_step_solve_kernel(MarlEnvParams P, M
     if ((int)blockIdx.x >= total) {
         // the histogram has been consumed by the order kernel: the last block clears it for the next step
         // (bins only: the other blocks of this launch still read the total)
-        if (blockIdx.x == gridDim.x - 1) {
-            S.solve_hist[lane] = 0;
-            if (lane == 0) S.solve_hist[WAVE] = 0;
-        }
+        if (blockIdx.x == gridDim.x - 1)
+            for (int k = lane; k < SOLVE_HIST_TOTAL; k += WAVE) S.solve_hist[k] = 0;
         return;
     }
     const int e = S.solve_perm[blockIdx.x];

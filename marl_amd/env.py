@@ -146,7 +146,7 @@ class BatchedJammerEnv:
                                                 C.c_void_p(base)), "marl_state_bind")
             dims = {"E": (self.E,), "EN": (self.E, self.N), "EM": (self.E, self.M), "EK": (self.E, self.N + 1)}
             self.views: Dict[str, torch.Tensor] = {}
-            dims["H"] = (128,)
+            dims["H"] = (1344,)
             for name, (dt, shp) in _STATE_SPEC.items():
                 if getattr(self.state, name) is None:
                     continue

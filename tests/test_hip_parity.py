@@ -660,5 +660,5 @@ def test_full_size_step_properties(mode):
         assert float(x.min()) >= 0 and float(x.max()) <= 200 and float(y.min()) >= 0 and float(y.max()) <= 200
         sp = (env.views["enemy_vx"] ** 2 + env.views["enemy_vy"] ** 2).sqrt()
         assert float((sp - 2.0).abs().max()) < 1e-9                               # both models keep the speed
-        assert int(env.views["solve_hist"][:65].abs().sum()) == 0                 # hand-over histogram left clean
+        assert int(env.views["solve_hist"][:1280].abs().sum()) == 0               # hand-over histograms left clean
     assert seen_solved > 0 and seen_complete > 0                                  # all three lambda2 routes ran
