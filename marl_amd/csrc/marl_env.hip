@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -60,21 +61,31 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p ? 1 : 0); }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+// Sums over the 64 lanes: rotate-and-add inside each row of 16 lanes with DPP moves (no LDS traffic,
+// unlike a shuffle butterfly, whose six ds_bpermute round trips cost several hundred cycles), then the
+// four row totals through SGPRs.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov32(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int wave_sum(int v) {
+    v += dpp_mov32<0x128>(v);      // row_ror:8
+    v += dpp_mov32<0x124>(v);      // row_ror:4
+    v += dpp_mov32<0x122>(v);      // row_ror:2
+    v += dpp_mov32<0x121>(v);      // row_ror:1
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+           (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += __int_as_float(dpp_mov32<0x128>(__float_as_int(v)));
+    v += __int_as_float(dpp_mov32<0x124>(__float_as_int(v)));
+    v += __int_as_float(dpp_mov32<0x122>(__float_as_int(v)));
+    v += __int_as_float(dpp_mov32<0x121>(__float_as_int(v)));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (a + b) + (c + d);
 }
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v);      // below, next to the 64-bit DPP helper
 __device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src); }
 
 // ------------------------------------------------------------------ counter-based generator
@@ -211,8 +222,6 @@ struct WaveLds {
     double sx[WAVE], sy[WAVE];        // enemy positions
     double2 sxy[WAVE];                // the same, interleaved: one 16-byte read per enemy in the pair loop
     double jx[WAVE], jy[WAVE];        // jammer positions
-    __attribute__((aligned(16))) double uvec[WAVE], qvec[WAVE];   // Householder vectors u, q
-    double2 de[WAVE];                 // tridiagonal: (diagonal, squared off-diagonal) per row
     unsigned long long xfer[WAVE];    // lane-to-lane hand-over of 64-bit rows
     double cx[WAVE + 2], cy[WAVE + 2];  // centroids in dict order
     double px[WAVE + 2], py[WAVE + 2];  // previous centroids
@@ -220,8 +229,12 @@ struct WaveLds {
     int lab[WAVE];
     int asg[WAVE];
     int jb[WAVE];
+    // eigen-solver only (kernels that do not solve allocate the struct up to here: front_lds_bytes)
+    __attribute__((aligned(16))) double uvec[WAVE], qvec[WAVE];   // Householder vectors u, q
+    double2 de[WAVE];                 // tridiagonal: (diagonal, squared off-diagonal) per row
 };
 
+inline size_t front_lds_bytes() { return offsetof(WaveLds, uvec); }
 inline size_t wave_lds_bytes(int) { return sizeof(WaveLds); }
 
 // ------------------------------------------------------------------ pairwise bit rows
@@ -370,6 +383,7 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     v += dpp_mov<0x121>(v);      // row_ror:1
     return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_dpp(v); }
 // The same when only lanes 0..last hold non-zero terms (last wave-uniform): rows of 16 lanes
 // beyond `last` are not visited.
 __device__ __forceinline__ double wave_sum_dpp_upto(double v, int last) {
@@ -491,20 +505,38 @@ __device__ __forceinline__ double sturm_largest_wave(const LDS& L, int np, int l
         if (hi - lo <= 2e-12 * hi) break;
         const double w = (hi - lo) * (1.0 / 65.0);
         const double x = lo + w * (double)(lane + 1);
+        // The signs of p_1, p_2, ... are shifted into a 64-bit register (two v_alignbit_b32 per term);
+        // with `fresh` new bits at the bottom, the sign changes they add are the set bits
+        // 0..fresh-1 of B ^ (B >> 1) (p_0 = 1 is the zero bit above p_1).  Flushed every 32 terms.
         double pm = 1.0, pc = L.de[0].x - x;
-        int cnt = (unsigned)__double2hiint(pc) >> 31;
-        for (int i = 1; i < np; ++i) {
+        uint32_t b_hi = 0, b_lo = (uint32_t)__double2hiint(pc) >> 31;
+        int cnt = 0, fresh = 1;
+        auto term = [&](int i) {
             const double2 t = L.de[i];
             const double pn = fma(t.x - x, pc, -(t.y * pm));
-            cnt += ((unsigned)(__double2hiint(pn) ^ __double2hiint(pc))) >> 31;
+            b_hi = __builtin_amdgcn_alignbit(b_hi, b_lo, 31);
+            b_lo = __builtin_amdgcn_alignbit(b_lo, (uint32_t)__double2hiint(pn), 31);
             pm = pc;
             pc = pn;
-            if ((i & 7) == 7) {                         // keep the recurrence inside the exponent range
-                const int ex = __builtin_amdgcn_frexp_exp(fabs(pc) > fabs(pm) ? pc : pm);
-                pc = ldexp(pc, -ex);
-                pm = ldexp(pm, -ex);
-            }
+        };
+        auto flush = [&]() {
+            const uint64_t B = ((uint64_t)b_hi << 32) | b_lo;
+            cnt += __popcll((B ^ (B >> 1)) & ((1ull << fresh) - 1));
+            fresh = 0;
+        };
+        int i = 1;
+        for (; i + 8 <= np; i += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) term(i + k);
+            fresh += 8;
+            if (fresh >= 32) flush();
+            // keep the recurrence inside the exponent range
+            const int ex = __builtin_amdgcn_frexp_exp(fabs(pc) > fabs(pm) ? pc : pm);
+            pc = ldexp(pc, -ex);
+            pm = ldexp(pm, -ex);
         }
+        for (; i < np; ++i) { term(i); ++fresh; }
+        flush();
         const uint64_t all = ballot64(cnt >= np);
         if (all == 0) {
             lo = readlane_d(x, WAVE - 1);
@@ -814,6 +846,7 @@ __device__ __forceinline__ RewardOut reward_obs_wave(const MarlEnvParams& P, int
     // two-Newton-step ones)
     double best2 = INFINITY;
     int bslot = 0;
+#pragma unroll 4
     for (int s = 0; s < ncent; ++s) {
         const double dx = xj - L.cx[s], dy = yj - L.cy[s];
         const double d2 = dx * dx + dy * dy;
@@ -824,6 +857,7 @@ __device__ __forceinline__ RewardOut reward_obs_wave(const MarlEnvParams& P, int
     const double thr = 2 * Rjam, thr2 = thr * thr;
     int ov = 0;
     double dsum = 0.0;
+#pragma unroll 4
     for (int k = 0; k < m; ++k) {
         const double dx = xj - L.jx[k], dy = yj - L.jy[k];
         const double d2 = dx * dx + dy * dy;
@@ -928,6 +962,14 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
     const int step = S.step_count[e] + 1;
     const int eband = S.enemy_band[e];
     const double arena = P.arena_size;
+#ifdef MARL_EXP_TIMING
+    float fsec[5] = {0, 0, 0, 0, 0};
+    uint64_t ft0, ft1;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ft0)::"memory");
+#define FSTAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ft1)::"memory"); fsec[k] = (float)(ft1 - ft0); ft0 = ft1; } while (0)
+#else
+#define FSTAMP(k)
+#endif
 
     // -- action decode (jammer_env.py:372-388, action_space.py:190-240)
     float raw_vx = 0.0f, raw_vy = 0.0f;
@@ -960,6 +1002,7 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
     }
     int num = S.n_clusters[e], ncent = S.ncent[e];
     WSYNC();
+    FSTAMP(0);
     // -- clusters: recompute every K steps (jammer_env.py:394-402), else load the table
     if (step % P.K_recompute == 0) {
         const int pnum = num, pncent = ncent;
@@ -994,19 +1037,18 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
         }
         WSYNC();
     }
+    FSTAMP(1);
     // -- lambda2 of the jammed graph (jammer_env.py:464-508)
     uint64_t adj, jam;
-#ifdef MARL_EXP_NO_PAIR
-    adj = (lane < n) ? (((1ull << n) - 1) & ~(1ull << lane)) : 0; jam = (lane < n) ? (0x5555555555ull >> lane) & adj & ((1ull << n) - 1) : 0;
-#else
     pair_rows(L, n, m, lane, eband, P.comm_d2_max[eband], P.jam_d2_max[eband], arena, adj, jam);
-#endif
     store_bits(io.adj_bits, e, n, lane, adj);
     store_bits(io.jam_bits, e, n, lane, jam);
+    FSTAMP(2);
     double lam;
     uint64_t crow;
     int np;
     const bool final_lam = lambda2_prepare(adj & ~jam, n, lane, L, lam, crow, np);
+    FSTAMP(3);
     const double lam0 = S.lambda2_initial[e];
     // -- reward, observation (jammer_env.py:414-438)
     const RewardOut rw = reward_obs_wave(P, n, m, lane, L, eband, num, ncent, lam, lam0, raw_vx, raw_vy);
@@ -1030,15 +1072,18 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
             io.reward[e] = (float)rw.total;
             if (io.lambda2) io.lambda2[e] = lam;
         } else {
-#ifdef MARL_EXP_NO_ATOMIC
-            S.solve_slot[e] = e;
-#else
             S.solve_slot[e] = atomicAdd(&S.solve_hist[(e & (SOLVE_HIST_SUBS - 1)) * SOLVE_HIST_STRIDE + np], 1);
-#endif
             double* part = S.solve_partial + (size_t)e * 4;
             part[0] = rw.d2; part[1] = rw.d3; part[2] = (double)rw.r3; part[3] = rw.d5;
         }
     }
+#ifdef MARL_EXP_TIMING
+    FSTAMP(4);
+    if (io.reward_terms && lane == 0) {
+        float* r = io.reward_terms + (size_t)e * 5;
+        r[0] = fsec[0]; r[1] = fsec[1]; r[2] = fsec[2]; r[3] = fsec[3]; r[4] = fsec[4];
+    }
+#endif
 }
 
 // Order: env indices of the pending solves into solve_perm, largest matrix first (a counting sort
@@ -1104,7 +1149,9 @@ __global__ __launch_bounds__(WAVE) void env_step_solve_kernel(MarlEnvParams P, M
         const double total_r = reward_total(P, lam, S.lambda2_initial[e], part[0], part[1], (float)part[2], part[3], r1);
         io.reward[e] = (float)total_r;
         if (io.lambda2) io.lambda2[e] = lam;
+#ifndef MARL_EXP_TIMING
         if (io.reward_terms) io.reward_terms[(size_t)e * 5] = (float)r1;
+#endif
     }
 }
 
@@ -2203,7 +2250,7 @@ int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepI
     if (s->solve_rows == nullptr || s->solve_np == nullptr || s->solve_slot == nullptr || s->solve_perm == nullptr ||
         s->solve_hist == nullptr || s->solve_partial == nullptr)
         return MARL_EINVAL;
-    hipLaunchKernelGGL(env_step_front_kernel, dim3(s->E), dim3(WAVE), wave_lds_bytes(p->N), (hipStream_t)stream, *p, *s, *io);
+    hipLaunchKernelGGL(env_step_front_kernel, dim3(s->E), dim3(WAVE), front_lds_bytes(), (hipStream_t)stream, *p, *s, *io);
     hipLaunchKernelGGL(solve_order_kernel, dim3((s->E + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, (int)s->E, *s);
     // one block more than envs: the last one never has a solve and clears the histogram
     MARL_DISPATCH_NPAD(p->N, env_step_solve_kernel, dim3(s->E + 1), 0, stream, *p, *s, *io);
