@@ -90,6 +90,8 @@ typedef struct MarlEnvState {
     int32_t *jam_band;
     float *last_vx, *last_vy;
     int32_t *step_count, *enemy_band;
+    int32_t *tick;             /* [E] steps taken since the state was created (never reset): keys the on-device
+                                  noise and reset draws, so that episodes of one env do not repeat each other */
     double *lambda2_initial;
     int32_t *labels;
     double *cent_x, *cent_y;

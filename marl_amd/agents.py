@@ -53,7 +53,8 @@ class Actor(nn.Module):
         """actor.py:146-202.  obs [..., obs_dim] -> actions [..., 3], log_prob [...], entropy [...]."""
         mu, log_std, logits = self.forward(obs)
         std = torch.exp(log_std)
-        vdist, bdist = Normal(mu, std), Categorical(logits=logits)
+        # validate_args=False: the argument checks read a flag back to the host at every call
+        vdist, bdist = Normal(mu, std, validate_args=False), Categorical(logits=logits, validate_args=False)
         if deterministic:
             velocity, band = mu, torch.argmax(logits, dim=-1)
         else:
@@ -71,7 +72,8 @@ class Actor(nn.Module):
     def evaluate_actions(self, obs, actions):
         """actor.py:204-247."""
         mu, log_std, logits = self.forward(obs)
-        vdist, bdist = Normal(mu, torch.exp(log_std)), Categorical(logits=logits)
+        vdist = Normal(mu, torch.exp(log_std), validate_args=False)
+        bdist = Categorical(logits=logits, validate_args=False)
         velocity = torch.clamp(actions[..., :2], -self.v_max * 2, self.v_max * 2)
         band = actions[..., 2].long()
         log_prob = vdist.log_prob(velocity).sum(dim=-1) + bdist.log_prob(band)
@@ -255,7 +257,7 @@ class PPOAgent:
     def __init__(self, obs_dim=5, hidden_dim=128, M=4, v_max=5.0, num_bands=4, log_std_min=-1.0, log_std_max=0.5,
                  gamma=0.99, gae_lambda=0.95, clip_eps=0.2, lr_actor=3e-4, lr_critic=1e-3, c1=0.5, c2=0.01,
                  max_grad_norm=0.5, rollout_length=2048, batch_size=256, n_epochs=10, device="auto", num_envs=1,
-                 seed: Optional[int] = None):
+                 seed: Optional[int] = None, graph_update: bool = True):
         self.obs_dim, self.hidden_dim, self.M, self.v_max, self.num_bands = obs_dim, hidden_dim, M, v_max, num_bands
         self.gamma, self.gae_lambda, self.clip_eps, self.c1, self.c2 = gamma, gae_lambda, clip_eps, c1, c2
         self.c2_initial, self.max_grad_norm = c2, max_grad_norm
@@ -270,8 +272,16 @@ class PPOAgent:
         if _dist_on():                       # every rank starts from rank 0's weights
             for p in list(self.actor.parameters()) + list(self.critic.parameters()):
                 torch.distributed.broadcast(p.data, src=0)
-        self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=lr_actor)
-        self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr=lr_critic)
+        # On the GPU one minibatch step (forward, backward, clipping, both Adam steps: about a hundred
+        # small launches for these 36 k parameters) is captured into a HIP graph and replayed, which
+        # needs capturable optimisers with their learning rates, and the entropy weight, in device memory.
+        self._graph_update = bool(graph_update) and self.device.type == "cuda" and not _dist_on()
+        on_gpu = self.device.type == "cuda"
+        mk_lr = (lambda v: torch.tensor(float(v), device=self.device)) if on_gpu else float
+        self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=mk_lr(lr_actor), capturable=on_gpu)
+        self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr=mk_lr(lr_critic), capturable=on_gpu)
+        self._c2_t = torch.tensor(float(c2), device=self.device)
+        self._step_graph, self._step_static, self._eager_steps = None, None, 0
         self._sync = FlatGradSync([self.actor, self.critic])
         self.buffer = None
         if self.device.type == "cuda":
@@ -334,6 +344,47 @@ class PPOAgent:
             self.training_stats[k].append(v)
         return stats
 
+    def _minibatch_step(self, b_obs, b_act, b_old, b_adv, b_ret) -> torch.Tensor:
+        """One optimiser step of ppo_agent.py:296-345; returns [actor_loss, critic_loss, entropy,
+        clip_fraction, approx_kl] as a float64 device tensor."""
+        log_probs, entropy = self.actor.evaluate_actions(b_obs, b_act)
+        values = self.critic.forward_pooled(b_obs).squeeze(-1)
+        ratio = torch.exp(log_probs - b_old)
+        surr1 = ratio * b_adv
+        surr2 = torch.clamp(ratio, 1 - self.clip_eps, 1 + self.clip_eps) * b_adv
+        actor_loss = -torch.min(surr1, surr2).mean()
+        critic_loss = self.c1 * ((values - b_ret) ** 2).mean()
+        entropy_loss = -self._c2_t * entropy.mean()
+        self.actor_optimizer.zero_grad(set_to_none=False)
+        self.critic_optimizer.zero_grad(set_to_none=False)
+        (actor_loss + entropy_loss).backward()
+        critic_loss.backward()
+        self._sync.sync()
+        nn.utils.clip_grad_norm_(self.actor.parameters(), self.max_grad_norm)
+        nn.utils.clip_grad_norm_(self.critic.parameters(), self.max_grad_norm)
+        self.actor_optimizer.step()
+        self.critic_optimizer.step()
+        with torch.no_grad():
+            kl = ((ratio - 1) - torch.log(ratio)).mean()
+            return torch.stack([actor_loss, critic_loss, entropy.mean(),
+                                (torch.abs(ratio - 1) > self.clip_eps).float().mean(), kl]).double()
+
+    def _graphed_step(self, batch):
+        """Replays the captured minibatch step on `batch` (tensors of exactly batch_size rows)."""
+        if self._step_graph is None:
+            self._step_static = [torch.empty_like(t) for t in batch]
+            for d, t in zip(self._step_static, batch):
+                d.copy_(t)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_out = self._minibatch_step(*self._step_static)
+            self._step_graph = g
+        for d, t in zip(self._step_static, batch):
+            d.copy_(t)
+        self._step_graph.replay()
+        return self._step_out
+
     def optimise(self, obs, actions, old_log_probs, advantages, returns, generator=None) -> Dict[str, float]:
         """The epoch / minibatch loop of ppo_agent.py:286-354 on flattened device tensors.  Works on
         any device; with torch.distributed initialised, gradients are averaged in one flat
@@ -348,30 +399,16 @@ class PPOAgent:
             nb = 0
             for s in range(0, n, self.batch_size):
                 idx = perm[s:s + self.batch_size]
-                b_obs, b_act = obs[idx], actions[idx]
-                b_old, b_adv, b_ret = old_log_probs[idx], advantages[idx], returns[idx]
-                log_probs, entropy = self.actor.evaluate_actions(b_obs, b_act)
-                values = self.critic.forward_pooled(b_obs).squeeze(-1)
-                ratio = torch.exp(log_probs - b_old)
-                surr1 = ratio * b_adv
-                surr2 = torch.clamp(ratio, 1 - self.clip_eps, 1 + self.clip_eps) * b_adv
-                actor_loss = -torch.min(surr1, surr2).mean()
-                critic_loss = self.c1 * ((values - b_ret) ** 2).mean()
-                entropy_loss = -self.c2 * entropy.mean()
-                self.actor_optimizer.zero_grad(set_to_none=False)
-                self.critic_optimizer.zero_grad(set_to_none=False)
-                (actor_loss + entropy_loss).backward()
-                critic_loss.backward()
-                self._sync.sync()
-                nn.utils.clip_grad_norm_(self.actor.parameters(), self.max_grad_norm)
-                nn.utils.clip_grad_norm_(self.critic.parameters(), self.max_grad_norm)
-                self.actor_optimizer.step()
-                self.critic_optimizer.step()
-                with torch.no_grad():
-                    kl = ((ratio - 1) - torch.log(ratio)).mean()
-                    acc += torch.stack([actor_loss, critic_loss, entropy.mean(),
-                                        (torch.abs(ratio - 1) > self.clip_eps).float().mean(), kl]).double()
-                    epoch_kl += kl.double()
+                batch = (obs[idx], actions[idx], old_log_probs[idx], advantages[idx], returns[idx])
+                # the first steps run eagerly (they create the optimiser state), short tail batches too
+                if self._graph_update and self._eager_steps >= 2 and idx.numel() == self.batch_size \
+                        and (self._step_static is None or self._step_static[0].shape[0] == self.batch_size):
+                    out = self._graphed_step(batch)
+                else:
+                    out = self._minibatch_step(*batch)
+                    self._eager_steps += 1
+                acc += out
+                epoch_kl += out[4]
                 nb += 1
                 steps += 1
             avg_kl = epoch_kl / max(nb, 1)
@@ -388,13 +425,16 @@ class PPOAgent:
 
     # -- schedule / mode / checkpoint (ppo_agent.py:375-484) ----------------------
     def set_learning_rate(self, lr_actor, lr_critic):
-        for g in self.actor_optimizer.param_groups:
-            g["lr"] = lr_actor
-        for g in self.critic_optimizer.param_groups:
-            g["lr"] = lr_critic
+        for opt, lr in ((self.actor_optimizer, lr_actor), (self.critic_optimizer, lr_critic)):
+            for g in opt.param_groups:
+                if isinstance(g["lr"], torch.Tensor):
+                    g["lr"].fill_(float(lr))          # in place: a captured step reads this tensor
+                else:
+                    g["lr"] = lr
 
     def set_entropy_coef(self, c2):
         self.c2 = c2
+        self._c2_t.fill_(float(c2))
 
     def set_training_mode(self, training=True):
         self.actor.train(training)

@@ -127,6 +127,13 @@ __device__ __forceinline__ void noise_pair(uint64_t seed, uint64_t genv, uint32_
     nx = rad * c; ny = rad * s;
 }
 
+// Counter word that tells one reset of an env from another in generator mode: the caller's episode
+// number mixed with the env's step clock (steps taken since the state was created; never reset), so
+// that a replayed launch sequence (HIP graph) still draws fresh values.
+__device__ __forceinline__ uint32_t episode_key(const MarlResetIO& io, const MarlEnvState& S, int e) {
+    return (uint32_t)io.episode ^ ((uint32_t)S.tick[e] * 0x9E3779B1u);
+}
+
 // np.mod(x, a) for a > 0 as numpy computes it for float64 (npy_divmod): C fmod, moved into [0, a).
 __device__ __forceinline__ double numpy_mod(double x, double a) {
     double r = fmod(x, a);
@@ -193,9 +200,9 @@ __device__ __forceinline__ void enemy_spawn(const MarlEnvParams& P, const MarlEn
     uint32_t r[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0};
     if (!host_init || (ct && io.enemy_omega == nullptr)) {
         philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)i << 8) ^ STREAM_RESET_ENEMY,
-                   (uint32_t)io.episode, (uint32_t)attempt, k0, k1, r);
+                   episode_key(io, S, e), (uint32_t)attempt, k0, k1, r);
         philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)i << 8) ^ STREAM_RESET_ENEMY,
-                   (uint32_t)io.episode, (uint32_t)attempt | 0x80000000u, k0, k1, r2);
+                   episode_key(io, S, e), (uint32_t)attempt | 0x80000000u, k0, k1, r2);
     }
     double x, y, vx, vy;
     if (host_init) {
@@ -1014,7 +1021,7 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
     // -- enemy dynamics (enemy_swarm.py:139-242)
     if (lane < n) {
         double x, y;
-        enemy_move(P, S, io, e, lane, step, x, y);
+        enemy_move(P, S, io, e, lane, S.tick[e] + 1, x, y);
         L.sx[lane] = x; L.sy[lane] = y;
         L.sxy[lane] = make_double2(x, y);
     }
@@ -1083,6 +1090,7 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
     if (!final_lam && lane < np) S.solve_rows[(size_t)e * WAVE + lane] = crow;
     if (lane == 0) {
         S.step_count[e] = step;
+        S.tick[e] = S.tick[e] + 1;
         io.truncated[e] = (uint8_t)(step >= P.max_steps);
         if (io.avg_power_dbm) io.avg_power_dbm[e] = avgp;
         S.solve_np[e] = np;
@@ -1199,7 +1207,7 @@ __global__ __launch_bounds__(WAVE) void env_reset_wave_kernel(MarlEnvParams P, M
             eband = io.enemy_band[e];
         } else {
             uint32_t r[4];
-            philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ STREAM_RESET_ENV, (uint32_t)io.episode,
+            philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ STREAM_RESET_ENV, episode_key(io, S, e),
                        (uint32_t)attempt, k0, k1, r);
             eband = (int)(r[0] & 3u);
         }
@@ -1245,9 +1253,9 @@ __global__ __launch_bounds__(WAVE) void env_reset_wave_kernel(MarlEnvParams P, M
         uint32_t r[4], r2[4];
         if (io.jam_init == nullptr || io.jam_band == nullptr) {
             philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)lane << 8) ^ STREAM_RESET_JAMMER,
-                       (uint32_t)io.episode, 0u, k0, k1, r);
+                       episode_key(io, S, e), 0u, k0, k1, r);
             philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)lane << 8) ^ STREAM_RESET_JAMMER,
-                       (uint32_t)io.episode, 1u, k0, k1, r2);
+                       episode_key(io, S, e), 1u, k0, k1, r2);
         }
         if (io.jam_init) { ix = io.jam_init[o * 2]; iy = io.jam_init[o * 2 + 1]; }
         else if (P.random_jammer_start) {
@@ -1381,7 +1389,7 @@ __global__ void fill_noise_kernel(MarlEnvParams P, MarlEnvState S, uint64_t seed
     if (i >= P.N) return;
     double nx, ny;
     const double sigma = P.enemy_mode == MARL_ENEMY_COORDINATED_TURN ? P.noise_std * 0.5 : P.noise_std;
-    noise_pair(seed, env_offset + e, (uint32_t)(S.step_count[e] + 1), (uint32_t)i, sigma, nx, ny);
+    noise_pair(seed, env_offset + e, (uint32_t)(S.tick[e] + 1), (uint32_t)i, sigma, nx, ny);
     noise[((size_t)e * P.N + i) * 2] = nx;
     noise[((size_t)e * P.N + i) * 2 + 1] = ny;
 }
@@ -1844,7 +1852,7 @@ __global__ __launch_bounds__(WAVE) void env_step_big_kernel(MarlEnvParams P, Mar
         const int i = s * WAVE + lane;
         if (i < n) {
             double x, y;
-            enemy_move(P, St, io, e, i, step, x, y);
+            enemy_move(P, St, io, e, i, St.tick[e] + 1, x, y);
             L.sx[i] = x; L.sy[i] = y;
         }
     }
@@ -1890,6 +1898,7 @@ __global__ __launch_bounds__(WAVE) void env_step_big_kernel(MarlEnvParams P, Mar
     if (io.avg_power_dbm) avgp = avg_power_big<S>(P, n, m, lane, L, eband);
     if (lane == 0) {
         St.step_count[e] = step;
+        St.tick[e] = St.tick[e] + 1;
         io.reward[e] = (float)rw.total;
         io.truncated[e] = (uint8_t)(step >= P.max_steps);
         if (io.lambda2) io.lambda2[e] = lam;
@@ -1927,7 +1936,7 @@ __global__ __launch_bounds__(WAVE) void env_reset_big_kernel(MarlEnvParams P, Ma
             eband = io.enemy_band[e];
         } else {
             uint32_t r[4];
-            philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ STREAM_RESET_ENV, (uint32_t)io.episode,
+            philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ STREAM_RESET_ENV, episode_key(io, St, e),
                        (uint32_t)attempt, k0, k1, r);
             eband = (int)(r[0] & 3u);
         }
@@ -1951,9 +1960,9 @@ __global__ __launch_bounds__(WAVE) void env_reset_big_kernel(MarlEnvParams P, Ma
         uint32_t r[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0};
         if (io.jam_init == nullptr || io.jam_band == nullptr) {
             philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)lane << 8) ^ STREAM_RESET_JAMMER,
-                       (uint32_t)io.episode, 0u, k0, k1, r);
+                       episode_key(io, St, e), 0u, k0, k1, r);
             philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)lane << 8) ^ STREAM_RESET_JAMMER,
-                       (uint32_t)io.episode, 1u, k0, k1, r2);
+                       episode_key(io, St, e), 1u, k0, k1, r2);
         }
         if (io.jam_init) { ix = io.jam_init[o * 2]; iy = io.jam_init[o * 2 + 1]; }
         else if (P.random_jammer_start) {
@@ -2198,7 +2207,7 @@ size_t marl_state_bytes(const MarlEnvParams* p, int32_t E) {
     b += 2 * align256(e * m * 8);        // jam x, y
     b += align256(e * m * 4);            // jam_band
     b += 2 * align256(e * m * 4);        // last_vx, last_vy
-    b += 2 * align256(e * 4);            // step_count, enemy_band
+    b += 3 * align256(e * 4);            // step_count, enemy_band, tick
     b += align256(e * 8);                // lambda2_initial
     b += align256(e * n * 4);            // labels
     b += 2 * align256(e * ks * 8);       // cent x, y
@@ -2233,6 +2242,7 @@ int marl_state_bind(MarlEnvState* s, const MarlEnvParams* p, int32_t E, void* ba
     s->jam_band = (int32_t*)take(e * m * 4);
     s->last_vx = (float*)take(e * m * 4); s->last_vy = (float*)take(e * m * 4);
     s->step_count = (int32_t*)take(e * 4); s->enemy_band = (int32_t*)take(e * 4);
+    s->tick = (int32_t*)take(e * 4);
     s->lambda2_initial = (double*)take(e * 8);
     s->labels = (int32_t*)take(e * n * 4);
     s->cent_x = (double*)take(e * ks * 8); s->cent_y = (double*)take(e * ks * 8);

@@ -97,7 +97,7 @@ _STATE_SPEC = {   # name -> (dtype, shape as function of (E, N, M))
     "enemy_omega": ("f64", "EN"),
     "jam_x": ("f64", "EM"), "jam_y": ("f64", "EM"), "jam_band": ("i32", "EM"),
     "last_vx": ("f32", "EM"), "last_vy": ("f32", "EM"),
-    "step_count": ("i32", "E"), "enemy_band": ("i32", "E"), "lambda2_initial": ("f64", "E"),
+    "step_count": ("i32", "E"), "enemy_band": ("i32", "E"), "tick": ("i32", "E"), "lambda2_initial": ("f64", "E"),
     "labels": ("i32", "EN"), "cent_x": ("f64", "EK"), "cent_y": ("f64", "EK"), "cent_size": ("i32", "EK"),
     "n_clusters": ("i32", "E"), "ncent": ("i32", "E"), "prev_x": ("f64", "EK"), "prev_y": ("f64", "EK"),
     "prev_n_clusters": ("i32", "E"), "prev_ncent": ("i32", "E"), "assign": ("i32", "EM"),

@@ -17,7 +17,8 @@ from .env import BatchedJammerEnv, EnvConfig
 
 class BatchedTrainer:
     def __init__(self, env_cfg: EnvConfig, num_envs: int, rollout_length: int = 64, total_timesteps: int = 10 ** 7,
-                 seed: int = 0, device="cuda", agent_kwargs: Optional[Dict[str, Any]] = None):
+                 seed: int = 0, device="cuda", agent_kwargs: Optional[Dict[str, Any]] = None,
+                 minibatches_per_epoch: int = 32, use_graph: bool = True):
         rank = torch.distributed.get_rank() if _dist_on() else 0
         self.world = torch.distributed.get_world_size() if _dist_on() else 1
         self.device = torch.device(device)
@@ -25,8 +26,12 @@ class BatchedTrainer:
         self.total_budget = total_timesteps
         self.env = BatchedJammerEnv(num_envs, env_cfg, seed=seed, device=self.device, auto_reset=True,
                                     env_offset=rank * num_envs)
+        # The reference's defaults (2048-step rollout of one env, M = 4, minibatches of 256:
+        # training/config.py:86-96) give 32 optimiser steps per epoch; a batched rollout holds E*T*M
+        # samples, so the minibatch grows with it and the number of steps per epoch stays the same.
+        samples = rollout_length * num_envs * env_cfg.M
         kw = dict(M=env_cfg.M, v_max=env_cfg.v_max, rollout_length=rollout_length, num_envs=num_envs,
-                  device=self.device, seed=seed)
+                  device=self.device, seed=seed, batch_size=max(256, samples // max(1, minibatches_per_epoch)))
         kw.update(agent_kwargs or {})
         self.agent = PPOAgent(**kw)
         self.total_timesteps = 0          # env-steps over all ranks
@@ -35,14 +40,21 @@ class BatchedTrainer:
         self._ep_reward = torch.zeros(num_envs, dtype=torch.float64, device=self.device)
         self._obs = None
         self._done = torch.zeros(num_envs, dtype=torch.bool, device=self.device)
+        # The T steps of a rollout (policy inference, step kernels, masked reset, bookkeeping: about
+        # 40 small launches per step) are captured once into a HIP graph and replayed: the loop is
+        # launch-bound from Python, and everything in it already works on fixed device buffers and
+        # draws its randomness from device-side counters.
+        self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        self._graph = None
+        self._eager_rollouts = 0
+        self._stats = torch.zeros(4, dtype=torch.float64, device=self.device)   # episodes, sum reward, sum reduction %, sum len
 
-    def collect_rollout(self) -> Dict[str, float]:
-        """trainer.py:185-294 for E envs: T steps, transitions written in place by the step kernel;
-        per-episode reward and lambda2 reduction are accumulated on the device."""
+    def _rollout_steps(self):
+        """trainer.py:185-294 for E envs: T steps, transitions written in place by the step kernels;
+        per-episode reward and lambda2 reduction are accumulated on the device.  Touches only
+        persistent tensors, so that the launch sequence can be captured and replayed."""
         env, agent = self.env, self.agent
-        if self._obs is None:
-            self._obs, _ = env.reset()
-        stats = torch.zeros(4, dtype=torch.float64, device=self.device)   # episodes, sum reward, sum reduction %, sum len
+        self._stats.zero_()
         obs = self._obs
         for _ in range(self.T):
             actions, rew_out, done_out, obs_out = agent.act_into_buffer(obs)
@@ -53,10 +65,36 @@ class BatchedTrainer:
             lam0 = info["episode_lambda2_initial"]
             red = torch.where(lam0 > 1e-10, 100.0 * (1.0 - info["lambda2_current"] / lam0), torch.zeros_like(lam0))
             d = truncated.double()
-            stats += torch.stack([d.sum(), (self._ep_reward * d).sum(), (red * d).sum(),
-                                  (info["episode_step"].double() * d).sum()])
+            self._stats += torch.stack([d.sum(), (self._ep_reward * d).sum(), (red * d).sum(),
+                                        (info["episode_step"].double() * d).sum()])
             self._ep_reward *= (1.0 - d)
-        self._obs, self._done = obs, truncated.clone()
+        self._obs.copy_(obs)
+        self._done.copy_(truncated)
+
+    def collect_rollout(self) -> Dict[str, float]:
+        env, agent = self.env, self.agent
+        if self._obs is None:
+            obs0, _ = env.reset()
+            self._obs = obs0.clone()
+        if not self.use_graph:
+            self._rollout_steps()
+        elif self._graph is None and self._eager_rollouts < 1:
+            self._rollout_steps()                          # first rollout eagerly: warms up every lazy initialisation
+            self._eager_rollouts += 1
+        else:
+            if self._graph is None:
+                pos, steps = agent.buffer.pos, agent.total_timesteps
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._rollout_steps()
+                self._graph = g
+                # capture runs nothing: put the host-side counters back and replay below
+                agent.buffer.pos, agent.buffer.full, agent.total_timesteps = pos, False, steps
+            self._graph.replay()
+            agent.buffer.pos, agent.buffer.full = self.T, True
+            agent.total_timesteps += self.T * self.E
+        stats = self._stats.clone()
         if _dist_on():
             torch.distributed.all_reduce(stats)
         self.total_timesteps += self.T * self.E * self.world
