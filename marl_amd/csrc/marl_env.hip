@@ -86,7 +86,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (a + b) + (c + d);
 }
 __device__ __forceinline__ double wave_sum(double v);      // below, next to the 64-bit DPP helper
-__device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src); }
 
 // ------------------------------------------------------------------ counter-based generator
 // Philox4x32-10 (Salmon et al., SC'11).  Counter = (env index, draw index, stream id, episode/step),

@@ -662,3 +662,24 @@ def test_full_size_step_properties(mode):
         assert float((sp - 2.0).abs().max()) < 1e-9                               # both models keep the speed
         assert int(env.views["solve_hist"][:1280].abs().sum()) == 0               # hand-over histograms left clean
     assert seen_solved > 0 and seen_complete > 0                                  # all three lambda2 routes ran
+
+
+def test_generated_noise_does_not_repeat_across_episodes():
+    """The device generator is keyed by the env's step clock, which a reset does not rewind: step k of
+    one episode and step k of the next draw different noise, and so do two resets of the same env even
+    when the host passes the same episode number (a replayed HIP graph does exactly that)."""
+    cfg = EnvConfig.fast_preset(N=20, M=4, max_steps=5)
+    env = BatchedJammerEnv(32, cfg, seed=2, auto_reset=False)
+    env.reset()
+    first = env.fill_noise().clone()
+    pos0 = env.views["enemy_x"].clone()
+    act = torch.zeros(32, 4, 3, device="cuda")
+    for _ in range(5):
+        env.step(act)
+    assert int(env.views["tick"].min()) == 5 and int(env.views["step_count"].max()) == 5
+    env._episode = 0                               # same host-side episode number as the first reset
+    env.reset()
+    assert int(env.views["step_count"].max()) == 0 and int(env.views["tick"].min()) == 5
+    assert not torch.equal(env.views["enemy_x"], pos0)
+    again = env.fill_noise()
+    assert float((again - first).abs().min()) > 0.0
