@@ -1142,7 +1142,9 @@ __global__ __launch_bounds__(1024) void solve_order_kernel(int E, MarlEnvState S
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < E) {
         const int np = S.solve_np[e];
-        if (np > 0) S.solve_perm[start[e & (SOLVE_HIST_SUBS - 1)][np] + S.solve_slot[e]] = e;
+        if (np > 0) {
+            S.solve_perm[start[e & (SOLVE_HIST_SUBS - 1)][np] + S.solve_slot[e]] = e;
+        }
     }
 }
 
@@ -1418,6 +1420,7 @@ struct BigLds {
 };
 
 __host__ __device__ inline int big_ld(int n) { return (n + 7) & ~7; }
+constexpr int TEAM_MAX_NP = 208;        // largest eigenproblem of the team solver (104 columns per thread)
 
 template <int S>
 __device__ __forceinline__ uint64_t word_mask(int n, int k) {      // valid vertex bits of word k
@@ -1500,7 +1503,11 @@ __device__ __forceinline__ void expand_big(const uint64_t (&rows)[S][S], const u
 
 template <int S>
 __device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int n, int lane, BigLds<S>& L, int rounds,
-                                              double* As) {
+                                              double* As, int* pending = nullptr) {
+    // `pending` non-null: an eigenproblem of 65..TEAM_MAX_NP vertices is not solved here; its compacted
+    // complement rows (np x S words) go to the head of `As`, *pending = np, and the team kernel
+    // (one workgroup of 512 threads per env, matrix in registers) takes over.  *pending = 0 otherwise.
+    if (pending) *pending = 0;
     if (n <= 1) return 0.0;
     uint64_t touched[S];
     int deg[S];
@@ -1564,6 +1571,12 @@ __device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int 
     if (np <= WAVE) {
         const uint64_t crow = (lane < np) ? L.xfer[lane * S] : 0ull;
         return (double)n - mu_max_compact_wave<WAVE>(crow, np, lane, L, rounds);
+    }
+    if (pending != nullptr && np <= TEAM_MAX_NP) {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(As);
+        for (int k = lane; k < np * S; k += WAVE) out[k] = L.xfer[k];
+        *pending = np;
+        return 0.0;
     }
     // ---- n' > 64: matrix in the global workspace, element (r, c) at As[c*ld + r]; lane owns rows r = s*64+lane
     const int ld = big_ld(n);
@@ -2026,9 +2039,135 @@ __global__ __launch_bounds__(WAVE) void pair_bits_big_kernel(MarlEnvParams P, co
     store_bits_big<S>(bits, e, n, lane, rows);
 }
 
+// ------------------------------------------------------------------ team solver (64 < n' <= 208)
+// One workgroup of 512 threads per eigenproblem, the matrix in registers: row r belongs to the
+// threads 2r and 2r+1 (neighbouring lanes), thread 2r+h holding the columns of parity h, column
+// c = 2k+h in a[k].  The Householder step is the one of mu_max_compact_wave: the column loops are
+// the same ColHalves templates over the local columns k <= l/2, u and q are published in LDS split by
+// column parity, the two half-row products meet by one DPP swap, and the sums over the rows go
+// through a wave sum plus one LDS word per wave.  Five workgroup barriers per step.
+constexpr int TEAM_THREADS = 512;
+constexpr int TEAM_WAVES = TEAM_THREADS / WAVE;
+constexpr int TEAM_ROWS = TEAM_THREADS / 2;
+
+template <int CH>
+struct TeamLds {
+    double colbuf[TEAM_ROWS];                                     // pivot column, one entry per row
+    __attribute__((aligned(16))) double uh[2][TEAM_ROWS / 2 + 8];  // u by column parity
+    __attribute__((aligned(16))) double qh[2][TEAM_ROWS / 2 + 8];  // q by column parity
+    double2 de[TEAM_ROWS];                                        // tridiagonal: (diagonal, squared off-diagonal)
+    double red[2][TEAM_WAVES];
+    int redi[TEAM_WAVES];
+};
+
+__device__ __forceinline__ double team_sum(double v, double (&red)[TEAM_WAVES], int wave, int lane) {
+    const double w = wave_sum_dpp(v);
+    if (lane == 0) red[wave] = w;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < TEAM_WAVES; ++k) t += red[k];
+    return t;
+}
+
+// mu_max of the complement Laplacian whose compacted rows (np x S words) are at `rows`; valid in every thread.
+template <int CH, int S>
+__device__ __forceinline__ double mu_max_team(const unsigned long long* rows, int np, TeamLds<CH>& L, int rounds) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & (WAVE - 1);
+    const int r = tid >> 1, h = tid & 1;
+    unsigned long long cw[S];
+    int cdeg = 0;
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+        cw[q] = (r < np) ? rows[(size_t)r * S + q] : 0ull;
+        cdeg += __popcll(cw[q]);
+    }
+    int dmax = cdeg;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
+    if (lane == 0) L.redi[wave] = dmax;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TEAM_WAVES; ++k) dmax = max(dmax, L.redi[k]);
+
+    double a[CH];
+    static_for<0, CH>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        const int c = 2 * k + h;
+        const unsigned long long word = cw[(c >> 6) < S ? (c >> 6) : 0];
+        const double off = ((c >> 6) < S) ? -(double)((word >> (c & 63)) & 1ull) : 0.0;
+        a[k] = (r < np) ? ((c == r) ? (double)cdeg : off) : 0.0;
+    });
+
+    for (int i = np - 1; i >= 2; --i) {
+        const int l = i - 1, lh = l >> 1;
+        const double mine = column_of<CH, 0, CH>(a, i >> 1);
+        const double other = dpp_mov<0xB1>(mine);                   // quad_perm [1,0,3,2]: the partner's value
+        const double v = (h == (i & 1)) ? mine : other;             // A[r][i]
+        if (h == 0) L.colbuf[r] = v;
+        __syncthreads();
+        const double aii = L.colbuf[i], f = L.colbuf[l];
+        double uj = (r <= l) ? v : 0.0;
+        const double hsum = team_sum(h == 0 ? uj * uj : 0.0, L.red[0], wave, lane);
+        if (tid == 0) L.de[i] = make_double2(aii, hsum);
+        const double sq = (hsum > 0.0) ? fast_sqrt(hsum) : 0.0;
+        const double g = (f >= 0.0) ? -sq : sq;
+        const double h2 = hsum - f * g;
+        const double hinv = (hsum > 0.0) ? fast_rcp(h2) : 0.0;
+        if (r == l) uj = f - g;
+        if (h == 0) L.uh[r & 1][r >> 1] = uj;
+        __syncthreads();
+        double p0 = 0.0, p1 = 0.0;
+        {
+            const double* uv = L.uh[h];
+            const double2 t0 = *reinterpret_cast<const double2*>(uv), t1 = *reinterpret_cast<const double2*>(uv + 2);
+            ColHalves<CH, 0>::matvec(a, uv, lh, p0, p1, t0, t1);
+        }
+        const double ps = p0 + p1;
+        const double pr = ps + dpp_mov<0xB1>(ps);
+        const double p = (r <= l) ? pr * hinv : 0.0;
+        const double K = team_sum(h == 0 ? uj * p : 0.0, L.red[1], wave, lane) * (0.5 * hinv);
+        const double qj = fma(-K, uj, p);
+        if (h == 0) L.qh[r & 1][r >> 1] = qj;
+        __syncthreads();
+        {
+            const double* uv = L.uh[h];
+            const double* qv = L.qh[h];
+            const double2 tu0 = *reinterpret_cast<const double2*>(uv), tu1 = *reinterpret_cast<const double2*>(uv + 2);
+            const double2 tq0 = *reinterpret_cast<const double2*>(qv), tq1 = *reinterpret_cast<const double2*>(qv + 2);
+            ColHalves<CH, 0>::update(a, uj, qj, lh, uv, qv, tu0, tu1, tq0, tq1);
+        }
+    }
+    // the remaining 2 x 2 block: A[1][1] is column 1 (parity 1, k = 0) of row 1, A[1][0] and A[0][0] are a[0]
+    if (tid == 3) L.colbuf[2] = a[0];
+    if (tid == 2) L.colbuf[1] = a[0];
+    if (tid == 0) L.colbuf[0] = a[0];
+    __syncthreads();
+    if (tid == 0) {
+        L.de[1] = make_double2(L.colbuf[2], L.colbuf[1] * L.colbuf[1]);
+        L.de[0] = make_double2(L.colbuf[0], 0.0);
+    }
+    __syncthreads();
+    const double lo = (double)(dmax + 1) * (1.0 - 1e-13) - 1e-13;
+    const double hi = (double)min(np, 2 * dmax) * (1.0 + 1e-13) + 1e-13;
+    return sturm_largest_wave(L, np, lane, lo, hi, rounds + 1);     // every wave redundantly: no barrier inside
+}
+
+// Stage op: lambda2 for the envs the wave kernel left pending (pend[e] = np > 0).
+template <int CH, int S>
+__global__ __launch_bounds__(TEAM_THREADS) void lambda2_team_kernel(int n, const int* pend, const double* ws,
+                                                                    size_t ws_stride, double* lambda2, int rounds) {
+    __shared__ TeamLds<CH> L;
+    const int e = blockIdx.x;
+    const int np = pend[e];
+    if (np <= 0) return;
+    const double mu = mu_max_team<CH, S>(reinterpret_cast<const unsigned long long*>(ws + (size_t)e * ws_stride), np, L, rounds);
+    if (threadIdx.x == 0) lambda2[e] = (double)n - mu;
+}
+
 template <int S>
 __global__ __launch_bounds__(WAVE) void lambda2_bits_big_kernel(int n, const uint32_t* bits, double* lambda2, int rounds,
-                                                                double* ws) {
+                                                                double* ws, int* pend) {
     extern __shared__ __align__(16) unsigned char smem[];
     BigLds<S>& L = *reinterpret_cast<BigLds<S>*>(smem);
     const int e = blockIdx.x, lane = threadIdx.x;
@@ -2051,8 +2190,12 @@ __global__ __launch_bounds__(WAVE) void lambda2_bits_big_kernel(int n, const uin
         }
     }
     const int ld = big_ld(n);
-    const double lam = lambda2_big<S>(rows, n, lane, L, rounds, ws + (size_t)e * ld * ld);
-    if (lane == 0) lambda2[e] = lam;
+    int pending;
+    const double lam = lambda2_big<S>(rows, n, lane, L, rounds, ws + (size_t)e * ld * ld, &pending);
+    if (lane == 0) {
+        pend[e] = pending;
+        if (!pending) lambda2[e] = lam;
+    }
 }
 
 template <int S>
@@ -2133,8 +2276,23 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 size_t workspace_bytes(int N, int E) {
     if (N <= WAVE) return 0;
     const size_t ld = (size_t)big_ld(N);
-    return (size_t)E * ld * ld * sizeof(double);
+    return (size_t)E * ld * ld * sizeof(double) + align256((size_t)E * sizeof(int));   // + pending list of the team solver
 }
+
+// The pending list sits behind the per-env regions.
+inline int* workspace_pending(double* ws, int N, int E) {
+    const size_t ld = (size_t)big_ld(N);
+    return reinterpret_cast<int*>(ws + (size_t)E * ld * ld);
+}
+
+// Team solver launch: 104 columns per thread beyond 128 vertices, 64 up to there.
+#define MARL_LAUNCH_TEAM(N, kern, E, stream, ...)                                                                   \
+    do {                                                                                                            \
+        const int s_ = ((N) + WAVE - 1) / WAVE;                                                                     \
+        if (s_ == 2) hipLaunchKernelGGL((kern<64, 2>), dim3(E), dim3(TEAM_THREADS), 0, (hipStream_t)(stream), __VA_ARGS__);      \
+        else if (s_ == 3) hipLaunchKernelGGL((kern<104, 3>), dim3(E), dim3(TEAM_THREADS), 0, (hipStream_t)(stream), __VA_ARGS__); \
+        else hipLaunchKernelGGL((kern<104, 4>), dim3(E), dim3(TEAM_THREADS), 0, (hipStream_t)(stream), __VA_ARGS__);             \
+    } while (0)
 
 #define MARL_DISPATCH_SLOTS(N, kern, grid, stream, ...)                                                            \
     switch (((N) + WAVE - 1) / WAVE) {                                                                             \
@@ -2341,8 +2499,12 @@ int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t* bits, double* l
     if (rounds <= 0) rounds = 8;
     if (N > WAVE) {
         if (workspace == nullptr) return MARL_EINVAL;
+        int* pend = workspace_pending((double*)workspace, N, E);
         MARL_DISPATCH_SLOTS(N, lambda2_bits_big_kernel, dim3(E), stream, (int)N, bits, lambda2, (int)rounds,
-                            (double*)workspace);
+                            (double*)workspace, pend);
+        const size_t ld = (size_t)big_ld(N);
+        MARL_LAUNCH_TEAM(N, lambda2_team_kernel, E, stream, (int)N, (const int*)pend, (const double*)workspace,
+                         ld * ld, lambda2, (int)rounds);
         return hip_check(hipGetLastError());
     }
     MARL_DISPATCH_NPAD(N, lambda2_bits_kernel, dim3(E), wave_lds_bytes(N), stream, (int)N, bits, lambda2, (int)rounds);

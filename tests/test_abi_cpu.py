@@ -84,7 +84,7 @@ def test_state_carving_is_disjoint_and_aligned():
     # N = 200: one 200 x 200 float64 matrix per env on top
     p2 = EnvConfig.fast_preset(N=200, M=16).to_params()
     n2 = lib.marl_state_bytes(C.byref(p2), E)
-    assert lib.marl_lambda2_workspace_bytes(200, E) == E * 200 * 200 * 8 and n2 > E * 200 * 200 * 8
+    assert E * 200 * 200 * 8 <= lib.marl_lambda2_workspace_bytes(200, E) <= E * 200 * 200 * 8 + 4096 and n2 > E * 200 * 200 * 8
     _lib.check(lib.marl_state_bind(C.byref(st), C.byref(p2), E, C.c_void_p(base)))
     assert st.workspace is not None and st.workspace + E * 200 * 200 * 8 <= base + n2
     assert st.solve_rows is None                      # the three-launch step is for N <= 64
