@@ -100,7 +100,9 @@ typedef struct MarlEnvState {
     double *prev_x, *prev_y;
     int32_t *prev_n_clusters, *prev_ncent;
     int32_t *assign;
-    double *workspace;         /* lambda2 scratch, [E][ld][ld] with ld = N rounded up to 8; NULL when N <= 64 */
+    double *workspace;         /* N > 64 only (NULL otherwise): [E][ld][ld] lambda2 scratch, ld = N rounded up to 8,
+                                  then int32 [E] sizes of the eigenproblems left to the second launch of a step
+                                  (one 512-thread workgroup per env with 65..208 touched vertices) */
     /* N <= 64: a step runs as three launches.  The front kernel does everything but the eigen-solve and
      * leaves, for the envs whose graph is neither complete nor disconnected, the compacted complement
      * rows; the order kernel sorts those envs by matrix size, largest first; the solve kernel works
@@ -112,7 +114,7 @@ typedef struct MarlEnvState {
     int32_t *solve_perm;       /* [E] env indices, largest eigenproblem first */
     int32_t *solve_hist;       /* [1344] 16 histograms of solve_np (80 words apart, envs spread by index to keep the
                                   atomics uncontended); [1280] = envs to solve in this step */
-    double *solve_partial;     /* [E][4] reward terms 2..5 awaiting the lambda2 term */
+    double *solve_partial;     /* [E][4] reward terms 2..5 awaiting the lambda2 term (every N) */
 } MarlEnvState;
 
 /* Inputs and outputs of one step.  Optional pointers may be NULL. */

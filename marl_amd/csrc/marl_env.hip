@@ -1421,6 +1421,12 @@ struct BigLds {
 
 __host__ __device__ inline int big_ld(int n) { return (n + 7) & ~7; }
 constexpr int TEAM_MAX_NP = 208;        // largest eigenproblem of the team solver (104 columns per thread)
+// The workspace of N > 64: E regions of ld x ld doubles (compacted rows for the team solver at their
+// head, or the whole matrix for the global-memory solver), then the list of pending matrix sizes.
+__host__ __device__ inline int* workspace_pending(double* ws, int N, int E) {
+    const size_t ld = (size_t)big_ld(N);
+    return reinterpret_cast<int*>(ws + (size_t)E * ld * ld);
+}
 
 template <int S>
 __device__ __forceinline__ uint64_t word_mask(int n, int k) {      // valid vertex bits of word k
@@ -1894,8 +1900,10 @@ __global__ __launch_bounds__(WAVE) void env_step_big_kernel(MarlEnvParams P, Mar
     for (int s = 0; s < S; ++s)
 #pragma unroll
         for (int k = 0; k < S; ++k) adj[s][k] &= ~jam[s][k];
+    // eigenproblems of 65..208 vertices are left to env_step_team_kernel, which also finishes the reward
     const int ld = big_ld(n);
-    const double lam = lambda2_big<S>(adj, n, lane, L, P.lambda2_rounds, St.workspace + (size_t)e * ld * ld);
+    int pending;
+    const double lam = lambda2_big<S>(adj, n, lane, L, P.lambda2_rounds, St.workspace + (size_t)e * ld * ld, &pending);
     const double lam0 = St.lambda2_initial[e];
     const RewardOut rw = reward_obs_wave(P, n, m, lane, L, eband, num, ncent, lam, lam0, raw_vx, raw_vy);
     if (lane < m) {
@@ -1911,12 +1919,19 @@ __global__ __launch_bounds__(WAVE) void env_step_big_kernel(MarlEnvParams P, Mar
     if (lane == 0) {
         St.step_count[e] = step;
         St.tick[e] = St.tick[e] + 1;
-        io.reward[e] = (float)rw.total;
         io.truncated[e] = (uint8_t)(step >= P.max_steps);
-        if (io.lambda2) io.lambda2[e] = lam;
         if (io.avg_power_dbm) io.avg_power_dbm[e] = avgp;
+        workspace_pending(St.workspace, n, St.E)[e] = pending;
+        if (pending) {
+            double* part = St.solve_partial + (size_t)e * 4;
+            part[0] = rw.d2; part[1] = rw.d3; part[2] = (double)rw.r3; part[3] = rw.d5;
+        } else {
+            io.reward[e] = (float)rw.total;
+            if (io.lambda2) io.lambda2[e] = lam;
+        }
     }
 }
+
 
 template <int S>
 __global__ __launch_bounds__(WAVE) void env_reset_big_kernel(MarlEnvParams P, MarlEnvState St, MarlResetIO io) {
@@ -2165,6 +2180,28 @@ __global__ __launch_bounds__(TEAM_THREADS) void lambda2_team_kernel(int n, const
     if (threadIdx.x == 0) lambda2[e] = (double)n - mu;
 }
 
+// Second launch of a step for 64 < N <= 256: the pending eigenproblems, one workgroup each, then the
+// reward of that env (term 1 and the clipped sum, as env_step_solve_kernel does for N <= 64).
+template <int CH, int S>
+__global__ __launch_bounds__(TEAM_THREADS) void env_step_team_kernel(MarlEnvParams P, MarlEnvState St, MarlStepIO io) {
+    __shared__ TeamLds<CH> L;
+    const int e = blockIdx.x;
+    const int np = workspace_pending(St.workspace, P.N, St.E)[e];
+    if (np <= 0) return;
+    const size_t ld = (size_t)big_ld(P.N);
+    const double mu = mu_max_team<CH, S>(reinterpret_cast<const unsigned long long*>(St.workspace + (size_t)e * ld * ld),
+                                         np, L, P.lambda2_rounds);
+    if (threadIdx.x == 0) {
+        const double lam = (double)P.N - mu;
+        const double* part = St.solve_partial + (size_t)e * 4;
+        double r1;
+        const double total_r = reward_total(P, lam, St.lambda2_initial[e], part[0], part[1], (float)part[2], part[3], r1);
+        io.reward[e] = (float)total_r;
+        if (io.lambda2) io.lambda2[e] = lam;
+        if (io.reward_terms) io.reward_terms[(size_t)e * 5] = (float)r1;
+    }
+}
+
 template <int S>
 __global__ __launch_bounds__(WAVE) void lambda2_bits_big_kernel(int n, const uint32_t* bits, double* lambda2, int rounds,
                                                                 double* ws, int* pend) {
@@ -2279,11 +2316,6 @@ size_t workspace_bytes(int N, int E) {
     return (size_t)E * ld * ld * sizeof(double) + align256((size_t)E * sizeof(int));   // + pending list of the team solver
 }
 
-// The pending list sits behind the per-env regions.
-inline int* workspace_pending(double* ws, int N, int E) {
-    const size_t ld = (size_t)big_ld(N);
-    return reinterpret_cast<int*>(ws + (size_t)E * ld * ld);
-}
 
 // Team solver launch: 104 columns per thread beyond 128 vertices, 64 up to there.
 #define MARL_LAUNCH_TEAM(N, kern, E, stream, ...)                                                                   \
@@ -2378,8 +2410,8 @@ size_t marl_state_bytes(const MarlEnvParams* p, int32_t E) {
         b += align256(e * WAVE * 8);         // solve_rows
         b += 3 * align256(e * 4);            // solve_np, solve_slot, solve_perm
         b += align256(SOLVE_HIST_WORDS * 4); // solve_hist
-        b += align256(e * 4 * 8);            // solve_partial
     }
+    b += align256(e * 4 * 8);                // solve_partial
     return b;
 }
 
@@ -2416,7 +2448,7 @@ int marl_state_bind(MarlEnvState* s, const MarlEnvParams* p, int32_t E, void* ba
     s->solve_slot = split ? (int32_t*)take(e * 4) : nullptr;
     s->solve_perm = split ? (int32_t*)take(e * 4) : nullptr;
     s->solve_hist = split ? (int32_t*)take(SOLVE_HIST_WORDS * 4) : nullptr;
-    s->solve_partial = split ? (double*)take(e * 4 * 8) : nullptr;
+    s->solve_partial = (double*)take(e * 4 * 8);
     return MARL_OK;
 }
 
@@ -2428,8 +2460,9 @@ int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepI
         io->truncated == nullptr || s->enemy_x == nullptr)
         return MARL_EINVAL;
     if (p->N > WAVE) {
-        if (s->workspace == nullptr) return MARL_EINVAL;
+        if (s->workspace == nullptr || s->solve_partial == nullptr) return MARL_EINVAL;
         MARL_DISPATCH_SLOTS(p->N, env_step_big_kernel, dim3(s->E), stream, *p, *s, *io);
+        MARL_LAUNCH_TEAM(p->N, env_step_team_kernel, s->E, stream, *p, *s, *io);
         return hip_check(hipGetLastError());
     }
     if (s->solve_rows == nullptr || s->solve_np == nullptr || s->solve_slot == nullptr || s->solve_perm == nullptr ||
