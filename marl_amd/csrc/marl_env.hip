@@ -2060,7 +2060,7 @@ __global__ __launch_bounds__(WAVE) void pair_bits_big_kernel(MarlEnvParams P, co
 // c = 2k+h in a[k].  The Householder step is the one of mu_max_compact_wave: the column loops are
 // the same ColHalves templates over the local columns k <= l/2, u and q are published in LDS split by
 // column parity, the two half-row products meet by one DPP swap, and the sums over the rows go
-// through a wave sum plus one LDS word per wave.  Five workgroup barriers per step.
+// through a wave sum plus one LDS word per wave.
 constexpr int TEAM_THREADS = 512;
 constexpr int TEAM_WAVES = TEAM_THREADS / WAVE;
 constexpr int TEAM_ROWS = TEAM_THREADS / 2;
@@ -2069,21 +2069,11 @@ template <int CH>
 struct TeamLds {
     double colbuf[TEAM_ROWS];                                     // pivot column, one entry per row
     __attribute__((aligned(16))) double uh[2][TEAM_ROWS / 2 + 8];  // u by column parity
-    __attribute__((aligned(16))) double qh[2][TEAM_ROWS / 2 + 8];  // q by column parity
+    __attribute__((aligned(16))) double qh[2][TEAM_ROWS / 2 + 8];  // p = A u / h by column parity
     double2 de[TEAM_ROWS];                                        // tridiagonal: (diagonal, squared off-diagonal)
     double red[2][TEAM_WAVES];
     int redi[TEAM_WAVES];
 };
-
-__device__ __forceinline__ double team_sum(double v, double (&red)[TEAM_WAVES], int wave, int lane) {
-    const double w = wave_sum_dpp(v);
-    if (lane == 0) red[wave] = w;
-    __syncthreads();
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < TEAM_WAVES; ++k) t += red[k];
-    return t;
-}
 
 // mu_max of the complement Laplacian whose compacted rows (np x S words) are at `rows`; valid in every thread.
 template <int CH, int S>
@@ -2114,16 +2104,23 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
         a[k] = (r < np) ? ((c == r) ? (double)cdeg : off) : 0.0;
     });
 
+    // Three workgroup barriers per step.  The rank-2 update is applied in the form
+    //   A -= u p^T + w u^T,  w = p - 2K u   (= u q^T + q u^T with q = p - K u),
+    // so that p can be published together with the partial sums of K instead of after them.
     for (int i = np - 1; i >= 2; --i) {
         const int l = i - 1, lh = l >> 1;
         const double mine = column_of<CH, 0, CH>(a, i >> 1);
         const double other = dpp_mov<0xB1>(mine);                   // quad_perm [1,0,3,2]: the partner's value
         const double v = (h == (i & 1)) ? mine : other;             // A[r][i]
+        double uj = (r <= l) ? v : 0.0;
+        const double hw = wave_sum_dpp(h == 0 ? uj * uj : 0.0);
         if (h == 0) L.colbuf[r] = v;
+        if (lane == 0) L.red[0][wave] = hw;
         __syncthreads();
         const double aii = L.colbuf[i], f = L.colbuf[l];
-        double uj = (r <= l) ? v : 0.0;
-        const double hsum = team_sum(h == 0 ? uj * uj : 0.0, L.red[0], wave, lane);
+        double hsum = 0.0;
+#pragma unroll
+        for (int k = 0; k < TEAM_WAVES; ++k) hsum += L.red[0][k];
         if (tid == 0) L.de[i] = make_double2(aii, hsum);
         const double sq = (hsum > 0.0) ? fast_sqrt(hsum) : 0.0;
         const double g = (f >= 0.0) ? -sq : sq;
@@ -2141,16 +2138,20 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
         const double ps = p0 + p1;
         const double pr = ps + dpp_mov<0xB1>(ps);
         const double p = (r <= l) ? pr * hinv : 0.0;
-        const double K = team_sum(h == 0 ? uj * p : 0.0, L.red[1], wave, lane) * (0.5 * hinv);
-        const double qj = fma(-K, uj, p);
-        if (h == 0) L.qh[r & 1][r >> 1] = qj;
+        const double kw = wave_sum_dpp(h == 0 ? uj * p : 0.0);
+        if (h == 0) L.qh[r & 1][r >> 1] = p;
+        if (lane == 0) L.red[1][wave] = kw;
         __syncthreads();
+        double ksum = 0.0;
+#pragma unroll
+        for (int k = 0; k < TEAM_WAVES; ++k) ksum += L.red[1][k];
+        const double wj = fma(-(ksum * hinv), uj, p);                 // p - 2K u,  K = ksum hinv / 2
         {
             const double* uv = L.uh[h];
-            const double* qv = L.qh[h];
+            const double* pv = L.qh[h];
             const double2 tu0 = *reinterpret_cast<const double2*>(uv), tu1 = *reinterpret_cast<const double2*>(uv + 2);
-            const double2 tq0 = *reinterpret_cast<const double2*>(qv), tq1 = *reinterpret_cast<const double2*>(qv + 2);
-            ColHalves<CH, 0>::update(a, uj, qj, lh, uv, qv, tu0, tu1, tq0, tq1);
+            const double2 tp0 = *reinterpret_cast<const double2*>(pv), tp1 = *reinterpret_cast<const double2*>(pv + 2);
+            ColHalves<CH, 0>::update(a, uj, wj, lh, uv, pv, tu0, tu1, tp0, tp1);
         }
     }
     // the remaining 2 x 2 block: A[1][1] is column 1 (parity 1, k = 0) of row 1, A[1][0] and A[0][0] are a[0]
