@@ -613,12 +613,13 @@ def _unpack_bits(bits, N):
     return ((w[:, :, j // 32] >> (j % 32)) & 1).bool()
 
 
-@pytest.mark.parametrize("mode", ["random_walk", "coordinated_turn"])
-def test_full_size_step_properties(mode):
-    """8 192 envs x (N=50, M=8), the benchmark's shard, device generator: size-independent properties of
-    every step output, and lambda2 against a batched float64 eigvalsh of the Laplacians rebuilt from the
-    kernel's own adjacency / mask bits."""
-    E, N, M = 8192, 50, 8
+@pytest.mark.parametrize("mode,E,N,M", [("random_walk", 8192, 50, 8), ("coordinated_turn", 8192, 50, 8),
+                                        ("random_walk", 1024, 200, 16), ("random_walk", 512, 100, 12)])
+def test_full_size_step_properties(mode, E, N, M):
+    """8 192 envs x (N=50, M=8), the benchmark's shard (and N = 200 / 100 batches for the two-launch
+    path of the large swarms), device generator: size-independent properties of every step output, and
+    lambda2 against a batched float64 eigvalsh of the Laplacians rebuilt from the kernel's own
+    adjacency / mask bits."""
     cfg = EnvConfig.fast_preset(N=N, M=M, enemy_mode=mode, max_steps=6)
     env = BatchedJammerEnv(E, cfg, seed=11, auto_reset=False, debug_bits=True)
     twin = BatchedJammerEnv(E, cfg, seed=11, auto_reset=False)
@@ -660,8 +661,11 @@ def test_full_size_step_properties(mode):
         assert float(x.min()) >= 0 and float(x.max()) <= 200 and float(y.min()) >= 0 and float(y.max()) <= 200
         sp = (env.views["enemy_vx"] ** 2 + env.views["enemy_vy"] ** 2).sqrt()
         assert float((sp - 2.0).abs().max()) < 1e-9                               # both models keep the speed
-        assert int(env.views["solve_hist"][:1280].abs().sum()) == 0               # hand-over histograms left clean
-    assert seen_solved > 0 and seen_complete > 0                                  # all three lambda2 routes ran
+        if N <= 64:
+            assert int(env.views["solve_hist"][:1280].abs().sum()) == 0           # hand-over histograms left clean
+    assert seen_solved > 0                                                        # the eigen-solver ran
+    if N <= 64:
+        assert seen_complete > 0
 
 
 def test_generated_noise_does_not_repeat_across_episodes():
