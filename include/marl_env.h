@@ -107,7 +107,7 @@ typedef struct MarlEnvState {
      * leaves, for the envs whose graph is neither complete nor disconnected, the compacted complement
      * rows; the order kernel sorts those envs by matrix size, largest first; the solve kernel works
      * through them in that order (longest job first keeps the CUs evenly loaded) and finishes the reward.
-     * The buffers must be zero before the first step; a step leaves solve_hist zero again. */
+     * A reset of every env (mask NULL) clears solve_hist; a step leaves it zero again. */
     uint64_t *solve_rows;      /* [E][64] complement adjacency row per compacted vertex */
     int32_t *solve_np;         /* [E] vertices in the eigenproblem, 0 = lambda2 already final */
     int32_t *solve_slot;       /* [E] rank of the env among those with the same solve_np */

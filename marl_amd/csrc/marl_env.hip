@@ -1188,12 +1188,17 @@ __global__ __launch_bounds__(WAVE) void env_reset_wave_kernel(MarlEnvParams P, M
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds& L = carve(smem);
     const int e = blockIdx.x, lane = threadIdx.x;
+    // a reset of every env also (re)initialises the step's hand-over histograms, so that a state
+    // buffer that was not zeroed by the caller becomes valid with its first full reset
+    if (io.mask == nullptr && e == 0 && S.solve_hist != nullptr)
+        for (int k = lane; k < SOLVE_HIST_WORDS; k += WAVE) S.solve_hist[k] = 0;
     if (io.mask && io.mask[e] == 0) return;
     const int n = P.N, m = P.M, KS = n + 1;
     const double arena = P.arena_size;
     const uint64_t genv = io.env_offset + e;
     const uint32_t k0 = (uint32_t)io.seed, k1 = (uint32_t)(io.seed >> 32);
     int num = S.n_clusters[e], ncent = S.ncent[e];
+    ncent = ncent < 0 ? 0 : (ncent > KS ? KS : ncent);       // an unzeroed buffer must not send the copy loops astray
     int eband = 2;
     double lam0 = 0.0;
     const bool host_init = io.enemy_pos != nullptr;
@@ -1944,6 +1949,7 @@ __global__ __launch_bounds__(WAVE) void env_reset_big_kernel(MarlEnvParams P, Ma
     const uint64_t genv = io.env_offset + e;
     const uint32_t k0 = (uint32_t)io.seed, k1 = (uint32_t)(io.seed >> 32);
     int num = St.n_clusters[e], ncent = St.ncent[e];
+    ncent = ncent < 0 ? 0 : (ncent > P.N + 1 ? P.N + 1 : ncent);
     int eband = 2;
     double lam0 = 0.0;
     const bool host_init = io.enemy_pos != nullptr;

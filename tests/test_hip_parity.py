@@ -687,3 +687,21 @@ def test_generated_noise_does_not_repeat_across_episodes():
     assert not torch.equal(env.views["enemy_x"], pos0)
     again = env.fill_noise()
     assert float((again - first).abs().min()) > 0.0
+
+
+def test_state_buffer_need_not_be_zeroed_before_the_first_full_reset():
+    """A full reset initialises everything a step reads, hand-over histograms included: a state carved
+    out of a buffer full of garbage gives the same trajectory as one carved out of zeros."""
+    cfg = EnvConfig.fast_preset(N=50, M=8)
+    a = BatchedJammerEnv(64, cfg, seed=4, auto_reset=False)
+    b = BatchedJammerEnv(64, cfg, seed=4, auto_reset=False)
+    b._buf.fill_(0x5A)
+    b.views["tick"].zero_()                       # the step clock keys the generator: same start for both
+    a.reset(); b.reset()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for _ in range(12):
+        act = (torch.rand(64, 8, 3, device="cuda", generator=g) - 0.5) * 10
+        oa, ra, _, _, ia = a.step(act)
+        ob, rb, _, _, ib = b.step(act)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb)
+        assert torch.equal(ia["lambda2_current"], ib["lambda2_current"])
