@@ -48,6 +48,9 @@ extern "C" {
 #define MARL_MAX_M 64           /* jammers per env */
 #define MARL_ENEMY_RANDOM_WALK 0        /* EnemySwarm._step_random_walk, enemy_swarm.py:157-189 */
 #define MARL_ENEMY_COORDINATED_TURN 1   /* EnemySwarm._step_coordinated_turn, enemy_swarm.py:191-242 */
+#define MARL_SCHEDULE_AUTO 0            /* fused for N <= 16 or fewer than 1024 envs, split otherwise */
+#define MARL_SCHEDULE_FUSED 1
+#define MARL_SCHEDULE_SPLIT 2
 
 enum {
     MARL_OK = 0,
@@ -68,7 +71,8 @@ typedef struct MarlEnvParams {
     int32_t max_reset_attempts;
     int32_t lambda2_rounds;          /* multisection rounds of the eigenvalue search (0 = default) */
     int32_t enemy_mode;              /* MARL_ENEMY_RANDOM_WALK or MARL_ENEMY_COORDINATED_TURN (jammer_env.py:103) */
-    int32_t pad_i32;
+    int32_t step_schedule;           /* N <= 64: MARL_SCHEDULE_AUTO, _FUSED (one launch, solve inside the wave that
+                                        stepped the env) or _SPLIT (three launches, longest solve first) */
     double arena_size, dt, v_max, v_enemy;
     double P_tx_w, P_sens_w, P_jam_w, P_thr_w;
     double omega[5];

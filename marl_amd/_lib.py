@@ -16,6 +16,7 @@ ASSIGN_NONE = -2
 MAX_N = 256
 MAX_M = 64
 ENEMY_RANDOM_WALK, ENEMY_COORDINATED_TURN = 0, 1
+SCHEDULE_AUTO, SCHEDULE_FUSED, SCHEDULE_SPLIT = 0, 1, 2
 
 MARL_OK, MARL_EINVAL, MARL_EUNSUPPORTED, MARL_EHIP = 0, -1, -2, -3
 
@@ -27,7 +28,7 @@ class MarlEnvParams(C.Structure):
         ("N", C.c_int32), ("M", C.c_int32),
         ("max_steps", C.c_int32), ("K_recompute", C.c_int32), ("min_samples", C.c_int32),
         ("random_jammer_start", C.c_int32), ("max_reset_attempts", C.c_int32),
-        ("lambda2_rounds", C.c_int32), ("enemy_mode", C.c_int32), ("pad_i32", C.c_int32),
+        ("lambda2_rounds", C.c_int32), ("enemy_mode", C.c_int32), ("step_schedule", C.c_int32),
         ("arena_size", C.c_double), ("dt", C.c_double), ("v_max", C.c_double), ("v_enemy", C.c_double),
         ("P_tx_w", C.c_double), ("P_sens_w", C.c_double), ("P_jam_w", C.c_double), ("P_thr_w", C.c_double),
         ("omega", C.c_double * 5),

@@ -978,6 +978,9 @@ enum { SOLVE_HIST_SUBS = 16, SOLVE_HIST_STRIDE = 80, SOLVE_HIST_TOTAL = SOLVE_HI
        SOLVE_HIST_WORDS = SOLVE_HIST_TOTAL + 64 };
 
 // Front half: everything of JammerEnv.step but the eigen-solve.
+// FUSED = 0: as described.  FUSED = NPAD > 0: the solve follows in the same wave (one launch per step): taken for
+// small batches and small swarms, where the extra launches cost more than the scheduling gains.
+template <int FUSED>
 __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds& L = carve(smem);
@@ -1071,7 +1074,14 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
     double lam;
     uint64_t crow;
     int np;
-    const bool final_lam = lambda2_prepare(adj & ~jam, n, lane, L, lam, crow, np);
+    bool final_lam = lambda2_prepare(adj & ~jam, n, lane, L, lam, crow, np);
+    if constexpr (FUSED > 0) {
+        if (!final_lam) {
+            lam = (double)n - mu_max_compact_wave<FUSED>(crow, np, lane, L, P.lambda2_rounds);
+            final_lam = true;
+            np = 0;
+        }
+    }
     FSTAMP(3);
     const double lam0 = S.lambda2_initial[e];
     // -- reward, observation (jammer_env.py:414-438)
@@ -1086,13 +1096,13 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
     }
     double avgp = 0.0;
     if (io.avg_power_dbm) avgp = avg_power_wave(P, n, m, lane, L, eband);
-    if (!final_lam && lane < np) S.solve_rows[(size_t)e * WAVE + lane] = crow;
+    if (FUSED == 0 && !final_lam && lane < np) S.solve_rows[(size_t)e * WAVE + lane] = crow;
     if (lane == 0) {
         S.step_count[e] = step;
         S.tick[e] = S.tick[e] + 1;
         io.truncated[e] = (uint8_t)(step >= P.max_steps);
         if (io.avg_power_dbm) io.avg_power_dbm[e] = avgp;
-        S.solve_np[e] = np;
+        if (FUSED == 0) S.solve_np[e] = np;
         if (final_lam) {
             io.reward[e] = (float)rw.total;
             if (io.lambda2) io.lambda2[e] = lam;
@@ -2378,7 +2388,7 @@ int marl_params_init(MarlEnvParams* p) {
     if (!(p->arena_size > 0) || !(p->dt > 0) || p->K_recompute < 1 || p->max_steps < 1) return MARL_EINVAL;
     if (p->enemy_mode != MARL_ENEMY_RANDOM_WALK && p->enemy_mode != MARL_ENEMY_COORDINATED_TURN) return MARL_EINVAL;
     if (!(p->omega_max > 0)) p->omega_max = 0.5;             // EnemySwarm default (enemy_swarm.py:60)
-    p->pad_i32 = 0;
+    if (p->step_schedule < MARL_SCHEDULE_AUTO || p->step_schedule > MARL_SCHEDULE_SPLIT) return MARL_EINVAL;
     for (int b = 0; b < MARL_NUM_BANDS; ++b) {
         const double wl = kSpeedOfLight / band_hz(b);
         p->comm_d2_max[b] = largest_reaching_d2(p->P_tx_w, wl, p->P_sens_w);
@@ -2475,7 +2485,13 @@ int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepI
     if (s->solve_rows == nullptr || s->solve_np == nullptr || s->solve_slot == nullptr || s->solve_perm == nullptr ||
         s->solve_hist == nullptr || s->solve_partial == nullptr)
         return MARL_EINVAL;
-    hipLaunchKernelGGL(env_step_front_kernel, dim3(s->E), dim3(WAVE), front_lds_bytes(), (hipStream_t)stream, *p, *s, *io);
+    const bool fused = p->step_schedule == MARL_SCHEDULE_FUSED ||
+                       (p->step_schedule == MARL_SCHEDULE_AUTO && (p->N <= 16 || s->E < 1024));
+    if (fused) {
+        MARL_DISPATCH_NPAD(p->N, env_step_front_kernel, dim3(s->E), wave_lds_bytes(p->N), stream, *p, *s, *io);
+        return hip_check(hipGetLastError());
+    }
+    hipLaunchKernelGGL(env_step_front_kernel<0>, dim3(s->E), dim3(WAVE), front_lds_bytes(), (hipStream_t)stream, *p, *s, *io);
     hipLaunchKernelGGL(solve_order_kernel, dim3((s->E + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, (int)s->E, *s);
     // one block more than envs: the last one never has a solve and clears the histogram
     MARL_DISPATCH_NPAD(p->N, env_step_solve_kernel, dim3(s->E + 1), 0, stream, *p, *s, *io);

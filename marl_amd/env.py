@@ -59,6 +59,7 @@ class EnvConfig:
     random_jammer_start: bool = False
     lambda2_rounds: int = 0
     omega_max: float = 0.5          # EnemySwarm default (enemy_swarm.py:60); JammerEnv does not expose it
+    step_schedule: str = "auto"     # N <= 64: "auto", "fused" (one launch per step) or "split" (three, longest solve first)
 
     @staticmethod
     def fast_preset(N: int = 10, M: int = 4, **kw) -> "EnvConfig":
@@ -74,6 +75,7 @@ class EnvConfig:
         p = MarlEnvParams()
         p.enemy_mode = _lib.ENEMY_COORDINATED_TURN if self.enemy_mode == "coordinated_turn" else _lib.ENEMY_RANDOM_WALK
         p.omega_max = float(self.omega_max)
+        p.step_schedule = {"auto": _lib.SCHEDULE_AUTO, "fused": _lib.SCHEDULE_FUSED, "split": _lib.SCHEDULE_SPLIT}[self.step_schedule]
         p.N, p.M = int(self.N), int(self.M)
         p.max_steps, p.K_recompute, p.min_samples = int(self.max_steps), int(self.K_recompute), int(self.min_samples)
         p.random_jammer_start = int(bool(self.random_jammer_start))
