@@ -220,6 +220,16 @@ int marl_gae(int32_t T, int32_t E, const float *rewards, const float *values, co
              const float *last_value, const float *last_done, double gamma, double lam,
              float *advantages, float *returns, void *stream);
 
+/* RewardCalculator.compute_per_agent (environment/reward.py:308-360, with _compute_single_proximity
+ * :362-396): per-jammer reward [E][M] float32, the lambda2 and overlap terms shared, band match,
+ * proximity and energy the jammer's own; no clipping.  The env's step does not call it.  Tables in the
+ * layout of MarlEnvState: cent_x / cent_y [E][N+1], vx / vy = last_vx / last_vy. */
+int marl_reward_per_agent(const MarlEnvParams *p, int32_t E, const double *lambda2, const double *lambda2_initial,
+                          const int32_t *enemy_band, const double *jam_x, const double *jam_y,
+                          const int32_t *jam_band, const float *vx, const float *vy, const double *cent_x,
+                          const double *cent_y, const int32_t *n_clusters, const int32_t *ncent,
+                          const int32_t *assign, float *rewards, void *stream);
+
 /* The enemy-noise draw the step kernel uses when MarlStepIO.noise is NULL,
  * written out as [E][N][2] for step numbers step_count[e] + 1. */
 int marl_fill_noise(const MarlEnvParams *p, const MarlEnvState *s, uint64_t seed,

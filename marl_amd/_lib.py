@@ -89,6 +89,8 @@ SYMBOLS = {
                               C.c_void_p]),
     "marl_gae": (C.c_int, [C.c_int32, C.c_int32, _pf, _pf, _pf, _pf, _pf, C.c_double, C.c_double, _pf, _pf,
                            C.c_void_p]),
+    "marl_reward_per_agent": (C.c_int, [C.POINTER(MarlEnvParams), C.c_int32, _pd, _pd, _pi, _pd, _pd, _pi, _pf, _pf,
+                                        _pd, _pd, _pi, _pi, _pi, _pf, C.c_void_p]),
     "marl_fill_noise": (C.c_int, [C.POINTER(MarlEnvParams), C.POINTER(MarlEnvState), C.c_uint64, C.c_uint64,
                                   _pd, C.c_void_p]),
 }

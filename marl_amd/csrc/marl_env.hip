@@ -1400,6 +1400,56 @@ __global__ void gae_kernel(int T, int E, const float* rewards, const float* valu
     }
 }
 
+// RewardCalculator.compute_per_agent (reward.py:308-360): lane j < M owns jammer j; the tables are
+// read from global memory (this is a stage op beside the step, which only needs the shared reward).
+__global__ __launch_bounds__(WAVE) void reward_per_agent_kernel(MarlEnvParams P, const double* lambda2,
+        const double* lambda2_initial, const int32_t* enemy_band, const double* jam_x, const double* jam_y,
+        const int32_t* jam_band, const float* vx, const float* vy, const double* cent_x, const double* cent_y,
+        const int32_t* n_clusters, const int32_t* ncent_arr, const int32_t* assign, float* rewards) {
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int n = P.N, m = P.M, KS = n + 1;
+    const int eband = enemy_band[e], num = n_clusters[e], ncent = ncent_arr[e];
+    const bool act = lane < m;
+    const size_t o = (size_t)e * m + (act ? lane : 0);
+    const double xj = jam_x[o], yj = jam_y[o];
+    const double* cx = cent_x + (size_t)e * KS;
+    const double* cy = cent_y + (size_t)e * KS;
+    // shared terms
+    const double lam = lambda2[e], lam0 = lambda2_initial[e];
+    double r1 = 0.0;
+    if (lam0 > 0.0) r1 = fmin(fmax(1.0 - ((lam > 0.0 ? lam : 0.0) / lam0), 0.0), 1.0);
+    const double thr = 2 * P.R_jam[eband];
+    int ov = 0;
+    for (int k = lane + 1; k < m; ++k) {
+        const double dx = xj - jam_x[(size_t)e * m + k], dy = yj - jam_y[(size_t)e * m + k];
+        if (sqrt(dx * dx + dy * dy) < thr) ++ov;
+    }
+    const int ovl = wave_sum(act ? ov : 0);
+    const double r5 = (m > 1) ? (double)ovl / ((double)(m * (m - 1)) / 2) : 0.0;
+    if (!act) return;
+    // own terms
+    const double rb = (jam_band[o] == eband) ? 1.0 : 0.0;
+    double rp = 0.0;
+    if (ncent > 0) {
+        const int c = assign[o];
+        int slot = -1;
+        if (c >= 0 && c < num) slot = c;
+        else if (c == -1 && ncent > num) slot = num;
+        if (slot < 0) {                                    // nearest, first minimum wins
+            double best = INFINITY;
+            for (int s2 = 0; s2 < ncent; ++s2) {
+                const double dx = xj - cx[s2], dy = yj - cy[s2];
+                const double d = sqrt(dx * dx + dy * dy);
+                if (d < best) { best = d; slot = s2; }
+            }
+        }
+        const double dx = xj - cx[slot], dy = yj - cy[slot];
+        rp = exp(-P.kappa * sqrt(dx * dx + dy * dy));
+    }
+    const float re = (vx[o] * vx[o] + vy[o] * vy[o]) / P.v_max_sq_f32;
+    rewards[o] = (float)(P.omega[0] * r1 + P.omega[1] * rb + P.omega[2] * rp - P.omega[3] * (double)re - P.omega[4] * r5);
+}
+
 __global__ void fill_noise_kernel(MarlEnvParams P, MarlEnvState S, uint64_t seed, uint64_t env_offset, double* noise) {
     const int e = blockIdx.x, i = threadIdx.x;
     if (i >= P.N) return;
@@ -2593,6 +2643,22 @@ int marl_gae(int32_t T, int32_t E, const float* rewards, const float* values, co
     hipLaunchKernelGGL(gae_kernel, dim3((E + block - 1) / block), dim3(block), 0, (hipStream_t)stream, (int)T,
                        (int)E, rewards, values, dones, last_value, last_done, (float)gamma, (float)(gamma * lam), advantages,
                        returns);
+    return hip_check(hipGetLastError());
+}
+
+int marl_reward_per_agent(const MarlEnvParams* p, int32_t E, const double* lambda2, const double* lambda2_initial,
+                          const int32_t* enemy_band, const double* jam_x, const double* jam_y, const int32_t* jam_band,
+                          const float* vx, const float* vy, const double* cent_x, const double* cent_y,
+                          const int32_t* n_clusters, const int32_t* ncent, const int32_t* assign, float* rewards,
+                          void* stream) {
+    int rc = check_sizes(p);
+    if (rc != MARL_OK) return rc;
+    if (E < 1 || !lambda2 || !lambda2_initial || !enemy_band || !jam_x || !jam_y || !jam_band || !vx || !vy ||
+        !cent_x || !cent_y || !n_clusters || !ncent || !assign || !rewards)
+        return MARL_EINVAL;
+    hipLaunchKernelGGL(reward_per_agent_kernel, dim3(E), dim3(WAVE), 0, (hipStream_t)stream, *p, lambda2,
+                       lambda2_initial, enemy_band, jam_x, jam_y, jam_band, vx, vy, cent_x, cent_y, n_clusters, ncent,
+                       assign, rewards);
     return hip_check(hipGetLastError());
 }
 

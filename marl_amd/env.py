@@ -260,6 +260,20 @@ class BatchedJammerEnv:
                                                    _stream()), "marl_env_reset")
         return obs, reward, self._terminated, truncated, info
 
+    def reward_per_agent(self) -> torch.Tensor:
+        """RewardCalculator.compute_per_agent (reward.py:308-360) for the current state and the lambda2 of
+        the last step: [E, M] float32."""
+        v = self.views
+        out = torch.empty(self.E, self.M, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.marl_reward_per_agent(
+                C.byref(self.params), self.E, self.lambda2.data_ptr(), v["lambda2_initial"].data_ptr(),
+                v["enemy_band"].data_ptr(), v["jam_x"].data_ptr(), v["jam_y"].data_ptr(), v["jam_band"].data_ptr(),
+                v["last_vx"].data_ptr(), v["last_vy"].data_ptr(), v["cent_x"].data_ptr(), v["cent_y"].data_ptr(),
+                v["n_clusters"].data_ptr(), v["ncent"].data_ptr(), v["assign"].data_ptr(), out.data_ptr(),
+                _stream()), "marl_reward_per_agent")
+        return out
+
     def fill_noise(self) -> torch.Tensor:
         """The enemy noise the next step() draws when called with noise=None."""
         out = torch.empty(self.E, self.N, 2, dtype=torch.float64, device=self.device)

@@ -493,6 +493,39 @@ def reward5(p: EnvParams, lambda2_current, lambda2_initial, jammer_bands, enemy_
     return float(np.clip(raw, -10.0, 10.0)), (r1, r2, float(r3), r4, r5)
 
 
+def reward_per_agent(p: EnvParams, lambda2_current, lambda2_initial, jammer_bands, enemy_band,
+                     jammer_positions, cs: ClusterState, velocities, assign, R_jam):
+    """RewardCalculator.compute_per_agent (reward.py:308-360) with _compute_single_proximity
+    (:362-396): the lambda2 and overlap terms are shared, band match, proximity and energy are the
+    agent's own; float32 result, no clipping."""
+    M = jammer_positions.shape[0]
+    if M == 0:
+        return np.array([])
+    if lambda2_initial <= 0:
+        r1 = 0.0
+    else:
+        r1 = float(np.clip(1.0 - (max(0, lambda2_current) / lambda2_initial), 0.0, 1.0))
+    r5 = overlap_fraction(jammer_positions, R_jam)
+    ids = cs.cent_ids()
+    w = p.omega
+    out = np.zeros(M, dtype=np.float32)
+    for j in range(M):
+        rb = 1.0 if jammer_bands[j] == enemy_band else 0.0
+        rp = 0.0
+        if cs.ncent > 0:
+            c = int(assign[j])
+            if c != ASSIGN_NONE and c in ids:
+                target = cs.cent_xy[ids.index(c)]
+            else:
+                s_, _ = _nearest_slot(jammer_positions[j], cs)
+                target = cs.cent_xy[s_]
+            diff = jammer_positions[j] - target
+            rp = np.exp(-p.kappa * math.sqrt(diff[0] * diff[0] + diff[1] * diff[1]))
+        re = np.sum(velocities[j] ** 2) / (p.v_max ** 2)
+        out[j] = w[0] * r1 + w[1] * rb + w[2] * rp - w[3] * re - w[4] * r5
+    return out
+
+
 def overlap_fraction(jammer_positions, R_jam) -> float:
     """reward.py:282-306 == observation.py:238-262."""
     M = jammer_positions.shape[0]

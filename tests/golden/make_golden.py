@@ -350,6 +350,51 @@ def make_trajectories():
     make_trajectory("n30m6_bigarena", 30, 6, 21, 200, "chase", **big)
 
 
+def make_per_agent():
+    """RewardCalculator.compute_per_agent (reward.py:308-360): not called by the env's step, but part of
+    the reward module's public functions."""
+    rng = np.random.RandomState(2024)
+    out = {}
+    idx = 0
+    for N, M in ((10, 4), (50, 8), (30, 6), (120, 16)):
+        for rep in range(10):
+            arena, band = 200.0, int(rng.randint(0, 4))
+            k = max(1, N // 8)
+            ctr = rng.uniform(0.15 * arena, 0.85 * arena, size=(k, 2))
+            epos = np.clip(ctr[rng.randint(0, k, size=N)] + rng.normal(0, 0.06 * arena, size=(N, 2)), 0, arena)
+            jpos = rng.uniform(0.1 * arena, 0.9 * arena, size=(M, 2))
+            if rep % 3 == 0:
+                jpos[1:] = jpos[0] + rng.normal(0, 3.0, size=(M - 1, 2))      # overlapping jammers
+            jb = rng.randint(0, 4, size=M).astype(np.int32)
+            vel = rng.uniform(-6, 6, size=(M, 2)).astype(np.float32)
+            lam0 = float(N)
+            lam = float(rng.uniform(-0.1, 1.2) * N)
+            if rep == 7:
+                lam0 = 0.0
+            cl = dbc.DBSCANClusterer(eps=25.0, min_samples=2, arena_size=arena)
+            labels, cents = cl.fit(epos)
+            sizes = cl.get_cluster_sizes()
+            ids, cxy, csz, ncent = flatten_clusters(N, cents, sizes)
+            assigns = dbc.assign_jammers_to_clusters(M, cents, sizes, strategy="proportional")
+            mode = rep % 3                      # 0: assignments, 1: empty dict, 2: None
+            R_jam = fspl.compute_jam_range(fspl.db_to_watts(20.0), fspl.db_to_watts(-40.0),
+                                           fspl.FREQUENCY_BANDS[band])
+            rc = ref_reward.RewardCalculator(v_max=5.0, R_jam=R_jam, arena_size=arena)
+            r = rc.compute_per_agent(lam, lam0, jb, band, jpos, cents, vel,
+                                     assigns if mode == 0 else ({} if mode == 1 else None))
+            d = dict(N=np.int32(N), M=np.int32(M), band=np.int32(band), jpos=jpos, jb=jb, vel=vel,
+                     lam=np.float64(lam), lam0=np.float64(lam0), cent_ids=ids, cent_xy=cxy, cent_size=csz,
+                     ncent=np.int32(ncent), n_clusters=np.int32(cl.n_clusters),
+                     assign=flatten_assign(M, assigns if mode == 0 else {}), R_jam=np.float64(R_jam),
+                     rewards=np.asarray(r, dtype=np.float32))
+            for k_, v in d.items():
+                out[f"c{idx}_{k_}"] = v
+            idx += 1
+    out["n_cases"] = np.int32(idx)
+    np.savez_compressed(os.path.join(OUT, "per_agent.npz"), **out)
+    print("per-agent reward cases:", idx)
+
+
 def make_ct_trajectories():
     """Second dynamics mode of the enemy swarm (enemy_swarm.py:191-242)."""
     fast = dict(FAST)
@@ -489,7 +534,10 @@ def make_edges():
 if __name__ == "__main__":
     if "--ct-only" in sys.argv:       # adds the coordinated-turn files without touching the others
         make_ct_trajectories()
+    elif "--per-agent-only" in sys.argv:
+        make_per_agent()
     else:
+        make_per_agent()
         make_stage()
         make_edges()
         make_trajectories()

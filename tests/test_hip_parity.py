@@ -730,3 +730,41 @@ def test_split_schedule_equals_fused_schedule_over_episodes():
         assert torch.equal(inf_["reward_terms"], ins["reward_terms"]), t
     assert torch.equal(envs[0].views["enemy_x"], envs[1].views["enemy_x"])
     assert int(envs[1].views["tick"].min()) == 130
+
+
+def test_reward_per_agent_matches_reference_vectors():
+    """marl_reward_per_agent against RewardCalculator.compute_per_agent outputs (tests/golden/per_agent.npz)."""
+    import ctypes as C
+    from marl_amd import _lib
+    lib = _lib.load()
+    z = gu.load("per_agent.npz")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for i in range(int(z["n_cases"])):
+        g = lambda k: z[f"c{i}_{k}"]
+        N, M = int(g("N")), int(g("M"))
+        p = EnvConfig.fast_preset(N=N, M=M).to_params()
+        assert abs(p.R_jam[int(g("band"))] - float(g("R_jam"))) < 1e-12
+        nc = int(g("ncent"))
+        cx = np.zeros((1, N + 1)); cy = np.zeros((1, N + 1))
+        cx[0, :nc] = g("cent_xy")[:nc, 0]; cy[0, :nc] = g("cent_xy")[:nc, 1]
+        t = dict(lam=dev(np.array([g("lam")]), torch.float64), lam0=dev(np.array([g("lam0")]), torch.float64),
+                 band=dev(np.array([g("band")]), torch.int32), jx=dev(g("jpos")[None, :, 0], torch.float64),
+                 jy=dev(g("jpos")[None, :, 1], torch.float64), jb=dev(g("jb")[None], torch.int32),
+                 vx=dev(g("vel")[None, :, 0], torch.float32), vy=dev(g("vel")[None, :, 1], torch.float32),
+                 cx=dev(cx, torch.float64), cy=dev(cy, torch.float64),
+                 ncl=dev(np.array([g("n_clusters")]), torch.int32), nce=dev(np.array([nc]), torch.int32),
+                 asg=dev(g("assign")[None], torch.int32))
+        out = torch.zeros(1, M, dtype=torch.float32, device="cuda")
+        _lib.check(lib.marl_reward_per_agent(C.byref(p), 1, t["lam"].data_ptr(), t["lam0"].data_ptr(),
+                                             t["band"].data_ptr(), t["jx"].data_ptr(), t["jy"].data_ptr(),
+                                             t["jb"].data_ptr(), t["vx"].data_ptr(), t["vy"].data_ptr(),
+                                             t["cx"].data_ptr(), t["cy"].data_ptr(), t["ncl"].data_ptr(),
+                                             t["nce"].data_ptr(), t["asg"].data_ptr(), out.data_ptr(), st))
+        np.testing.assert_allclose(out[0].cpu().numpy(), g("rewards"), rtol=1e-5, atol=2e-6)
+    # and from a live env: the mean over the agents relates to the shared reward's terms
+    env = BatchedJammerEnv(16, EnvConfig.fast_preset(N=20, M=4), seed=1, auto_reset=False)
+    env.reset()
+    _, rew, _, _, info = env.step(torch.zeros(16, 4, 3, device="cuda"))
+    pa = env.reward_per_agent()
+    assert pa.shape == (16, 4)
+    np.testing.assert_allclose(pa.mean(1).cpu().numpy(), rew.cpu().numpy(), rtol=1e-5, atol=2e-6)

@@ -189,6 +189,18 @@ def test_reward_and_obs_sentinels():
     assert abs(obs[0, 0] - math.hypot(100, 100) / 200) < 1e-6
 
 
+def test_reward_per_agent():
+    z = gu.load("per_agent.npz")
+    for i in range(int(z["n_cases"])):
+        g = lambda k: z[f"c{i}_{k}"]
+        N, M = int(g("N")), int(g("M"))
+        p = orc.EnvParams.fast_preset(N=N, M=M)
+        cs = gu.cluster_state_from(N, g("cent_ids"), g("cent_xy"), g("cent_size"), g("ncent"))
+        r = orc.reward_per_agent(p, float(g("lam")), float(g("lam0")), g("jb"), int(g("band")), g("jpos"), cs,
+                                 g("vel"), g("assign"), float(g("R_jam")))
+        np.testing.assert_allclose(r, g("rewards"), rtol=2e-6, atol=2e-7)
+
+
 # ---------------------------------------------------------------- trajectories
 @pytest.mark.parametrize("name", gu.TRAJ_NAMES + gu.CT_TRAJ_NAMES)
 def test_trajectory(name):
