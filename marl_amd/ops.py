@@ -9,6 +9,7 @@ The stage ops mirror the reference's pure functions:
     lambda2_from_bits   physics/communication_graph.py:184-286  compute_laplacian + compute_lambda2
     dbscan_labels       clustering/dbscan_clustering.py:78-144  DBSCANClusterer.fit
     gae                 agents/rollout_buffer.py:151-204        compute_returns_and_advantages
+    reward_per_agent    environment/reward.py:308-396           RewardCalculator.compute_per_agent
     env_step            environment/jammer_env.py:356-457       JammerEnv.step (state mutated in place)
 
 Bit matrices are int32 tensors [E, N, ceil(N/32)]: row i, bit j of word j // 32.
@@ -147,6 +148,23 @@ def gae(rewards: torch.Tensor, values: torch.Tensor, dones: torch.Tensor, last_v
 @gae.register_fake
 def _(rewards, values, dones, last_value, last_done, gamma=0.99, lam=0.95):
     return [torch.empty_like(rewards), torch.empty_like(rewards)]
+
+
+@torch.library.custom_op("marl_amd::reward_per_agent", mutates_args=())
+def reward_per_agent(state: torch.Tensor, handle: int, lambda2: torch.Tensor) -> torch.Tensor:
+    """Per-jammer reward [E,M] float32 of the registered env's current state for the given lambda2 [E] f64."""
+    env = _ENVS[handle]
+    if state.data_ptr() != env._buf.data_ptr():
+        raise ValueError("state must be the buffer of the registered env")
+    _check_dev(lambda2)
+    env.lambda2.copy_(lambda2)
+    return env.reward_per_agent()
+
+
+@reward_per_agent.register_fake
+def _(state, handle, lambda2):
+    env = _ENVS[handle]
+    return lambda2.new_empty((env.E, env.M), dtype=torch.float32)
 
 
 # -- the step itself: state lives in a BatchedJammerEnv, addressed by a small integer handle -------

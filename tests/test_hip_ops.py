@@ -65,3 +65,5 @@ def test_env_step_op_mutates_registered_state():
         torch.ops.marl_amd.env_step(b._buf, h, act, None, obs, rew, tr)
         assert torch.equal(oa, obs) and torch.equal(ra, rew)
         assert torch.equal(a.views["enemy_x"], b.views["enemy_x"])
+    pa = torch.ops.marl_amd.reward_per_agent(b._buf, h, b.lambda2.clone())
+    assert pa.shape == (32, 4) and torch.equal(pa, a.reward_per_agent())
