@@ -1535,6 +1535,113 @@ __device__ __forceinline__ void pair_rows_big(uint64_t (&rows)[S][S], const BigL
     }
 }
 
+// The step's version of the two passes above, fused: one loop over the enemies builds the adjacency and
+// the jamming words of a 64-column chunk, with the jamming test in the scaled form of pair_pass (exact, see
+// there) for up to four matching jammers at a time, and without the adjacency test when the communication
+// range covers the arena (`arena` > 0 enables that shortcut; positions inside a step lie in [0, A]^2).
+template <int KJ, bool ADJ, int S>
+__device__ __forceinline__ void pair_chunk_big(const BigLds<S>& L, double xi, double yi, int base, int cnt,
+                                               double thr_comm, double thr_jam4, const double (&q2x)[4],
+                                               const double (&q2y)[4], uint64_t& aw, uint64_t& jw) {
+    uint32_t a_lo = 0, a_hi = 0, j_lo = 0, j_hi = 0;
+    auto body = [&](int b, uint32_t bit, uint32_t& a, uint32_t& jm) {
+        const double xj = L.sx[base + b], yj = L.sy[base + b];
+        if constexpr (ADJ) {
+            const double dx = xi - xj, dy = yi - yj;
+            a |= (dx * dx + dy * dy <= thr_comm) ? bit : 0u;
+        }
+        if constexpr (KJ > 0) {
+            const double sx = xi + xj, sy = yi + yj;
+            bool hit = false;
+            static_for<0, KJ>([&](auto k) {
+                const double DX = q2x[decltype(k)::value] - sx, DY = q2y[decltype(k)::value] - sy;
+                hit |= (DX * DX + DY * DY <= thr_jam4);
+            });
+            jm |= hit ? bit : 0u;
+        }
+    };
+    const int c_lo = cnt < 32 ? cnt : 32;
+    for (int b = 0; b < c_lo; ++b) body(b, 1u << b, a_lo, j_lo);
+    for (int b = 32; b < cnt; ++b) body(b, 1u << (b - 32), a_hi, j_hi);
+    if constexpr (ADJ) aw = ((uint64_t)a_hi << 32) | a_lo;
+    jw |= ((uint64_t)j_hi << 32) | j_lo;
+}
+
+template <int S>
+__device__ __forceinline__ void pair_rows_big_fused(uint64_t (&adj)[S][S], uint64_t (&jam)[S][S], const BigLds<S>& L,
+                                                    int n, int m, int lane, int eband, double d2_comm, double d2_jam,
+                                                    double arena) {
+    const bool all_linked = arena > 0.0 && d2_comm >= 2.000001 * arena * arena;
+    const double thr4 = 4.0 * d2_jam;
+    uint64_t mm = ballot64(lane < m && L.jb[lane] == eband);
+    double q2x[4], q2y[4];
+    auto next_four = [&]() {
+        int taken = 0;
+        static_for<0, 4>([&](auto k) {
+            double x = 1e300, y = 1e300;           // squares overflow to +inf: never within range
+            if (mm) {
+                const int j = __ffsll((unsigned long long)mm) - 1;
+                mm &= mm - 1;
+                x = 2.0 * L.jx[j]; y = 2.0 * L.jy[j];
+                ++taken;
+            }
+            q2x[decltype(k)::value] = x; q2y[decltype(k)::value] = y;
+        });
+        return taken;
+    };
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int k = 0; k < S; ++k) { adj[s][k] = 0; jam[s][k] = 0; }
+    bool first = true;
+    do {
+        const int kj = next_four();
+        const bool with_adj = first && !all_linked;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int i = s * WAVE + lane;
+            const double xi = L.sx[i], yi = L.sy[i];
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                const int cnt = min(WAVE, n - k * WAVE);
+                if (cnt <= 0) continue;
+                uint64_t aw = 0, jw = jam[s][k];
+                if (with_adj) {
+                    switch (kj) {
+                        case 0: pair_chunk_big<0, true, S>(L, xi, yi, k * WAVE, cnt, d2_comm, thr4, q2x, q2y, aw, jw); break;
+                        case 1: pair_chunk_big<1, true, S>(L, xi, yi, k * WAVE, cnt, d2_comm, thr4, q2x, q2y, aw, jw); break;
+                        case 2: pair_chunk_big<2, true, S>(L, xi, yi, k * WAVE, cnt, d2_comm, thr4, q2x, q2y, aw, jw); break;
+                        case 3: pair_chunk_big<3, true, S>(L, xi, yi, k * WAVE, cnt, d2_comm, thr4, q2x, q2y, aw, jw); break;
+                        default: pair_chunk_big<4, true, S>(L, xi, yi, k * WAVE, cnt, d2_comm, thr4, q2x, q2y, aw, jw); break;
+                    }
+                    adj[s][k] = aw;
+                } else if (kj > 0) {
+                    switch (kj) {
+                        case 1: pair_chunk_big<1, false, S>(L, xi, yi, k * WAVE, cnt, d2_comm, thr4, q2x, q2y, aw, jw); break;
+                        case 2: pair_chunk_big<2, false, S>(L, xi, yi, k * WAVE, cnt, d2_comm, thr4, q2x, q2y, aw, jw); break;
+                        case 3: pair_chunk_big<3, false, S>(L, xi, yi, k * WAVE, cnt, d2_comm, thr4, q2x, q2y, aw, jw); break;
+                        default: pair_chunk_big<4, false, S>(L, xi, yi, k * WAVE, cnt, d2_comm, thr4, q2x, q2y, aw, jw); break;
+                    }
+                }
+                jam[s][k] = jw;
+            }
+        }
+        first = false;
+    } while (mm);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = s * WAVE + lane;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            uint64_t keep = (i < n) ? word_mask<S>(n, k) : 0ull;
+            if (k == s) keep &= ~(1ull << lane);
+            if (all_linked) adj[s][k] = keep;
+            else adj[s][k] &= keep;
+            jam[s][k] &= keep;
+        }
+    }
+}
+
 template <int S>
 __device__ __forceinline__ void store_bits_big(uint32_t* dst, int e, int n, int lane, const uint64_t (&rows)[S][S]) {
     if (dst == nullptr) return;
@@ -1957,8 +2064,7 @@ __global__ __launch_bounds__(WAVE) void env_step_big_kernel(MarlEnvParams P, Mar
         WSYNC();
     }
     uint64_t adj[S][S], jam[S][S];
-    pair_rows_big<S, false>(adj, L, n, m, lane, eband, P.comm_d2_max[eband]);
-    pair_rows_big<S, true>(jam, L, n, m, lane, eband, P.jam_d2_max[eband]);
+    pair_rows_big_fused<S>(adj, jam, L, n, m, lane, eband, P.comm_d2_max[eband], P.jam_d2_max[eband], arena);
     store_bits_big<S>(io.adj_bits, e, n, lane, adj);
     store_bits_big<S>(io.jam_bits, e, n, lane, jam);
 #pragma unroll
