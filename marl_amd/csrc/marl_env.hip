@@ -2279,16 +2279,24 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
     // Three workgroup barriers per step.  The rank-2 update is applied in the form
     //   A -= u p^T + w u^T,  w = p - 2K u   (= u q^T + q u^T with q = p - K u),
     // so that p can be published together with the partial sums of K instead of after them.
+#ifdef MARL_EXP_TIMING
+    double tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tlast;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+#endif
     for (int i = np - 1; i >= 2; --i) {
         const int l = i - 1, lh = l >> 1;
-        const double mine = column_of<CH, 0, CH>(a, i >> 1);
+        double mine = column_of<CH, 0, CH>(a, i >> 1);
+        TSTAMP(0, mine);
         const double other = dpp_mov<0xB1>(mine);                   // quad_perm [1,0,3,2]: the partner's value
         const double v = (h == (i & 1)) ? mine : other;             // A[r][i]
         double uj = (r <= l) ? v : 0.0;
         const double hw = wave_sum_dpp(h == 0 ? uj * uj : 0.0);
         if (h == 0) L.colbuf[r] = v;
         if (lane == 0) L.red[0][wave] = hw;
+        TSTAMP(1, uj);
         __syncthreads();
+        TSTAMP(2, uj);
         const double aii = L.colbuf[i], f = L.colbuf[l];
         double hsum = 0.0;
 #pragma unroll
@@ -2300,6 +2308,7 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
         const double hinv = (hsum > 0.0) ? fast_rcp(h2) : 0.0;
         if (r == l) uj = f - g;
         if (h == 0) L.uh[r & 1][r >> 1] = uj;
+        TSTAMP(3, uj);
         __syncthreads();
         double p0 = 0.0, p1 = 0.0;
         {
@@ -2307,6 +2316,7 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
             const double2 t0 = *reinterpret_cast<const double2*>(uv), t1 = *reinterpret_cast<const double2*>(uv + 2);
             ColHalves<CH, 0>::matvec(a, uv, lh, p0, p1, t0, t1);
         }
+        TSTAMP(4, p0);
         const double ps = p0 + p1;
         const double pr = ps + dpp_mov<0xB1>(ps);
         const double p = (r <= l) ? pr * hinv : 0.0;
@@ -2314,6 +2324,7 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
         if (h == 0) L.qh[r & 1][r >> 1] = p;
         if (lane == 0) L.red[1][wave] = kw;
         __syncthreads();
+        TSTAMP(5, uj);
         double ksum = 0.0;
 #pragma unroll
         for (int k = 0; k < TEAM_WAVES; ++k) ksum += L.red[1][k];
@@ -2325,7 +2336,15 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
             const double2 tp0 = *reinterpret_cast<const double2*>(pv), tp1 = *reinterpret_cast<const double2*>(pv + 2);
             ColHalves<CH, 0>::update(a, uj, wj, lh, uv, pv, tu0, tu1, tp0, tp1);
         }
+        TSTAMP(6, a[0]);
     }
+#ifdef MARL_EXP_TIMING
+    {
+        double r_ = 0.0;
+        static_for<0, 8>([&](auto k) { if ((blockIdx.x & 7) == decltype(k)::value) r_ = tacc[decltype(k)::value]; });
+        return r_;
+    }
+#endif
     // the remaining 2 x 2 block: A[1][1] is column 1 (parity 1, k = 0) of row 1, A[1][0] and A[0][0] are a[0]
     if (tid == 3) L.colbuf[2] = a[0];
     if (tid == 2) L.colbuf[1] = a[0];
