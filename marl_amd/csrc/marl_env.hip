@@ -141,19 +141,13 @@ __device__ __forceinline__ double numpy_mod(double x, double a) {
     return r;
 }
 
-// EnemySwarm.step for drone i of env e (enemy_swarm.py:139-155): loads its state, moves it by the
-// random walk (:157-189) or the coordinated-turn model (:191-242), stores it, returns the position.
-__device__ __forceinline__ void enemy_move(const MarlEnvParams& P, const MarlEnvState& S, const MarlStepIO& io,
-                                           int e, int i, int step, double& xo, double& yo) {
-    const size_t o = (size_t)e * P.N + i;
+// One drone's move given its state and its noise draw(s): the random walk (:157-189) or the
+// coordinated-turn model (:191-242).  Pure arithmetic; `w` is the turn rate (coordinated turn only).
+__device__ __forceinline__ void enemy_advance(const MarlEnvParams& P, double& x, double& y, double& vx, double& vy,
+                                              double& w, double nx, double ny) {
     const double arena = P.arena_size;
-    const bool ct = P.enemy_mode == MARL_ENEMY_COORDINATED_TURN;
-    double nx, ny;
-    if (io.noise) { nx = io.noise[o * 2]; ny = io.noise[o * 2 + 1]; }
-    else noise_pair(io.seed, io.env_offset + e, (uint32_t)step, (uint32_t)i, ct ? P.noise_std * 0.5 : P.noise_std, nx, ny);
-    double x = S.enemy_x[o], y = S.enemy_y[o], vx = S.enemy_vx[o], vy = S.enemy_vy[o];
-    if (ct) {
-        const double w = S.enemy_omega[o], dt = P.dt;
+    if (P.enemy_mode == MARL_ENEMY_COORDINATED_TURN) {
+        const double dt = P.dt;
         double x1, y1, vx1, vy1;
         if (fabs(w) < 1e-6) {
             x1 = x + vx * dt; y1 = y + vy * dt; vx1 = vx; vy1 = vy;
@@ -165,7 +159,7 @@ __device__ __forceinline__ void enemy_move(const MarlEnvParams& P, const MarlEnv
             y1 = y + ((1 - cs) / w) * vx + (sn / w) * vy;
             vy1 = sn * vx + cs * vy;
         }
-        S.enemy_omega[o] = fmin(fmax(w + nx, -P.omega_max), P.omega_max);
+        w = fmin(fmax(w + nx, -P.omega_max), P.omega_max);
         x = numpy_mod(x1, arena); y = numpy_mod(y1, arena); vx = vx1; vy = vy1;
     } else {
         vx = vx + nx; vy = vy + ny;
@@ -181,6 +175,21 @@ __device__ __forceinline__ void enemy_move(const MarlEnvParams& P, const MarlEnv
         x = fmin(fmax(x, 0.0), arena);
         y = fmin(fmax(y, 0.0), arena);
     }
+}
+
+// EnemySwarm.step for drone i of env e (enemy_swarm.py:139-155): loads its state, moves it, stores it,
+// returns the position.  `tick` keys the generated noise.
+__device__ __forceinline__ void enemy_move(const MarlEnvParams& P, const MarlEnvState& S, const MarlStepIO& io,
+                                           int e, int i, int tick, double& xo, double& yo) {
+    const size_t o = (size_t)e * P.N + i;
+    const bool ct = P.enemy_mode == MARL_ENEMY_COORDINATED_TURN;
+    double nx, ny;
+    if (io.noise) { nx = io.noise[o * 2]; ny = io.noise[o * 2 + 1]; }
+    else noise_pair(io.seed, io.env_offset + e, (uint32_t)tick, (uint32_t)i, ct ? P.noise_std * 0.5 : P.noise_std, nx, ny);
+    double x = S.enemy_x[o], y = S.enemy_y[o], vx = S.enemy_vx[o], vy = S.enemy_vy[o];
+    double w = ct ? S.enemy_omega[o] : 0.0;
+    enemy_advance(P, x, y, vx, vy, w, nx, ny);
+    if (ct) S.enemy_omega[o] = w;
     S.enemy_x[o] = x; S.enemy_y[o] = y; S.enemy_vx[o] = vx; S.enemy_vy[o] = vy;
     xo = x; yo = y;
 }
@@ -998,42 +1007,65 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
 #define FSTAMP(k)
 #endif
 
+    // Every load of the step is issued here, ahead of any arithmetic (indices clamped so that all lanes
+    // load): with a handful of waves per SIMD a load that waits behind a dependent chain costs a
+    // microsecond each time.
+    const bool ct = P.enemy_mode == MARL_ENEMY_COORDINATED_TURN;
+    const size_t oj = (size_t)e * m + (lane < m ? lane : m - 1);
+    const size_t oi = (size_t)e * n + (lane < n ? lane : n - 1);
+    const float* act_p = io.actions + oj * 3;
+    const float a0 = act_p[0], a1 = act_p[1], a2 = act_p[2];
+    const double jx0 = S.jam_x[oj], jy0 = S.jam_y[oj];
+    const int asg0 = S.assign[oj];
+    double ex = S.enemy_x[oi], ey = S.enemy_y[oi], evx = S.enemy_vx[oi], evy = S.enemy_vy[oi];
+    double ew = ct ? S.enemy_omega[oi] : 0.0;
+    double nx = 0.0, ny = 0.0;
+    if (io.noise) { nx = io.noise[oi * 2]; ny = io.noise[oi * 2 + 1]; }
+    const int tick = S.tick[e] + 1;
+    int num = S.n_clusters[e], ncent = S.ncent[e];
+    const double lam0 = S.lambda2_initial[e];
+    const size_t oc = (size_t)e * KS + (lane < KS ? lane : KS - 1);
+    const double ccx = S.cent_x[oc], ccy = S.cent_y[oc];
+    const int ccs = S.cent_size[oc];
+
     // -- action decode (jammer_env.py:372-388, action_space.py:190-240)
     float raw_vx = 0.0f, raw_vy = 0.0f;
     if (lane < m) {
-        const float* a = io.actions + ((size_t)e * m + lane) * 3;
-        raw_vx = a[0]; raw_vy = a[1];
-        int band = (int)a[2];                                  // astype(int32): truncation
+        raw_vx = a0; raw_vy = a1;
+        int band = (int)a2;                                    // astype(int32): truncation
         band = band < 0 ? 0 : (band > MARL_NUM_BANDS - 1 ? MARL_NUM_BANDS - 1 : band);
         const float cvx = fminf(fmaxf(raw_vx, -P.v_max_f32), P.v_max_f32);
         const float cvy = fminf(fmaxf(raw_vy, -P.v_max_f32), P.v_max_f32);
         const float sx_ = cvx * P.dt_f32, sy_ = cvy * P.dt_f32;   // float32 product, as numpy does for f32 actions
-        double x = S.jam_x[(size_t)e * m + lane] + (double)sx_;
-        double y = S.jam_y[(size_t)e * m + lane] + (double)sy_;
+        double x = jx0 + (double)sx_;
+        double y = jy0 + (double)sy_;
         x = fmin(fmax(x, 0.0), arena);
         y = fmin(fmax(y, 0.0), arena);
-        S.jam_x[(size_t)e * m + lane] = x;
-        S.jam_y[(size_t)e * m + lane] = y;
-        S.jam_band[(size_t)e * m + lane] = band;
-        S.last_vx[(size_t)e * m + lane] = raw_vx;
-        S.last_vy[(size_t)e * m + lane] = raw_vy;
+        S.jam_x[oj] = x;
+        S.jam_y[oj] = y;
+        S.jam_band[oj] = band;
+        S.last_vx[oj] = raw_vx;
+        S.last_vy[oj] = raw_vy;
         L.jx[lane] = x; L.jy[lane] = y; L.jb[lane] = band;
-        L.asg[lane] = S.assign[(size_t)e * m + lane];
+        L.asg[lane] = asg0;
     }
     // -- enemy dynamics (enemy_swarm.py:139-242)
     if (lane < n) {
-        double x, y;
-        enemy_move(P, S, io, e, lane, S.tick[e] + 1, x, y);
-        L.sx[lane] = x; L.sy[lane] = y;
-        L.sxy[lane] = make_double2(x, y);
+        if (!io.noise)
+            noise_pair(io.seed, io.env_offset + e, (uint32_t)tick, (uint32_t)lane, ct ? P.noise_std * 0.5 : P.noise_std, nx, ny);
+        enemy_advance(P, ex, ey, evx, evy, ew, nx, ny);
+        if (ct) S.enemy_omega[oi] = ew;
+        S.enemy_x[oi] = ex; S.enemy_y[oi] = ey; S.enemy_vx[oi] = evx; S.enemy_vy[oi] = evy;
+        L.sx[lane] = ex; L.sy[lane] = ey;
+        L.sxy[lane] = make_double2(ex, ey);
     }
-    int num = S.n_clusters[e], ncent = S.ncent[e];
     WSYNC();
     FSTAMP(0);
     // -- clusters: recompute every K steps (jammer_env.py:394-402), else load the table
     if (step % P.K_recompute == 0) {
         const int pnum = num, pncent = ncent;
-        for (int s = lane; s < pncent; s += WAVE) {      // centroids -> _prev_centroids
+        if (lane < pncent) { L.px[lane] = ccx; L.py[lane] = ccy; }    // centroids -> _prev_centroids
+        for (int s = WAVE + lane; s < pncent; s += WAVE) {
             L.px[s] = S.cent_x[(size_t)e * KS + s];
             L.py[s] = S.cent_y[(size_t)e * KS + s];
         }
@@ -1057,7 +1089,8 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
             if (lane < m) S.assign[(size_t)e * m + lane] = L.asg[lane];
         }
     } else {
-        for (int s = lane; s < ncent; s += WAVE) {
+        if (lane < ncent) { L.cx[lane] = ccx; L.cy[lane] = ccy; L.csz[lane] = ccs; }
+        for (int s = WAVE + lane; s < ncent; s += WAVE) {      // N = 64 with a noise entry: 65 rows
             L.cx[s] = S.cent_x[(size_t)e * KS + s];
             L.cy[s] = S.cent_y[(size_t)e * KS + s];
             L.csz[s] = S.cent_size[(size_t)e * KS + s];
@@ -1083,7 +1116,6 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
         }
     }
     FSTAMP(3);
-    const double lam0 = S.lambda2_initial[e];
     // -- reward, observation (jammer_env.py:414-438)
     const RewardOut rw = reward_obs_wave(P, n, m, lane, L, eband, num, ncent, lam, lam0, raw_vx, raw_vy);
     if (lane < m) {
@@ -1099,7 +1131,7 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
     if (FUSED == 0 && !final_lam && lane < np) S.solve_rows[(size_t)e * WAVE + lane] = crow;
     if (lane == 0) {
         S.step_count[e] = step;
-        S.tick[e] = S.tick[e] + 1;
+        S.tick[e] = tick;
         io.truncated[e] = (uint8_t)(step >= P.max_steps);
         if (io.avg_power_dbm) io.avg_power_dbm[e] = avgp;
         if (FUSED == 0) S.solve_np[e] = np;
