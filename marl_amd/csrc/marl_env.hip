@@ -494,6 +494,58 @@ struct ColHalves {
     }
 };
 
+// The same column loops with the broadcasts taken from registers instead of LDS.  u (and q) are held
+// replicated, U[k] of lane t = u[16 k + t % 16], so that column c = 16 k + i is lane i of every row of
+// 16 lanes of U[k]: the DPP control row_newbcast:i of v_fmac_f64_dpp hands exactly that to all
+// lanes, inside the multiply-add.  One VALU instruction per column and term, no LDS read.
+// The DPP operand must not have been written by the VALU in the two preceding instructions: U and
+// Q come from LDS reads, and the first instruction of each chain carries an s_nop.
+template <int I, bool FIRST>
+__device__ __forceinline__ void fmac_row_bcast(double& d, const double& rowsrc, const double& m) {
+    if constexpr (FIRST)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(d) : "v"(rowsrc), "v"(m), "n"(I));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(d) : "v"(rowsrc), "v"(m), "n"(I));
+}
+template <int NPAD, int B>
+struct ColBlocks {
+    static constexpr int C0 = B * 8, KB = (NPAD + 15) / 16;
+    // p += A[:, 8B..8B+7] * u[8B..8B+7]
+    static __device__ __forceinline__ void matvec(const double (&a)[NPAD], const double (&U)[KB], int l,
+                                                  double& p0, double& p1) {
+        if constexpr (C0 < NPAD) {
+            if constexpr (B > 0) {
+                if (C0 > l) return;
+            }
+            static_for<0, 8>([&](auto jj) {
+                constexpr int c = C0 + decltype(jj)::value;
+                if constexpr (c < NPAD) fmac_row_bcast<c % 16, (c < 2)>((c & 1) ? p1 : p0, U[c / 16], a[c]);
+            });
+            ColBlocks<NPAD, B + 1>::matvec(a, U, l, p0, p1);
+        }
+    }
+    // A[:, c] -= u q_c + q u_c for c = 8B..8B+7; nuj = -u_lane, nqj = -q_lane
+    static __device__ __forceinline__ void update(double (&a)[NPAD], const double& nuj, const double& nqj, int l,
+                                                  const double (&U)[KB], const double (&Q)[KB]) {
+        if constexpr (C0 < NPAD) {
+            if constexpr (B > 0) {
+                if (C0 > l) return;
+            }
+            static_for<0, 8>([&](auto jj) {
+                constexpr int c = C0 + decltype(jj)::value;
+                if constexpr (c < NPAD) fmac_row_bcast<c % 16, (c < 2)>(a[c], Q[c / 16], nuj);
+            });
+            static_for<0, 8>([&](auto jj) {
+                constexpr int c = C0 + decltype(jj)::value;
+                if constexpr (c < NPAD) fmac_row_bcast<c % 16, false>(a[c], U[c / 16], nqj);
+            });
+            ColBlocks<NPAD, B + 1>::update(a, nuj, nqj, l, U, Q);
+        }
+    }
+};
+
 // a[i] for a wave-uniform runtime i in [LO, HI): binary search by uniform branches.  (Publishing
 // the pivot row through LDS instead costs a 16-byte store per column pair for the whole wave and
 // made the LDS pipe the bottleneck.)
@@ -588,6 +640,7 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
 
+    constexpr int KB = (NPAD + 15) / 16;
     double a[NPAD];                                   // row `lane` of the matrix
     static_for<0, NPAD>([&](auto k) {
         constexpr int c = decltype(k)::value;
@@ -620,10 +673,9 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
         TSTAMP(2, uj);
         // p = A u / h
         double p0 = 0.0, p1 = 0.0;
-        {
-            const double2 t0 = *reinterpret_cast<const double2*>(L.uvec), t1 = *reinterpret_cast<const double2*>(L.uvec + 2);
-            ColHalves<NPAD, 0>::matvec(a, L.uvec, l, p0, p1, t0, t1);
-        }
+        double U[KB], Q[KB];
+        static_for<0, KB>([&](auto k) { U[decltype(k)::value] = L.uvec[decltype(k)::value * 16 + (lane & 15)]; });
+        ColBlocks<NPAD, 0>::matvec(a, U, l, p0, p1);
         TSTAMP(3, p0);
         const double hinv = (h > 0.0) ? fast_rcp(h2) : 0.0;
         double p = (lane <= l) ? (p0 + p1) * hinv : 0.0;
@@ -635,9 +687,9 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
         WSYNC();
         TSTAMP(5, qj);
         {
-            const double2 tu0 = *reinterpret_cast<const double2*>(L.uvec), tu1 = *reinterpret_cast<const double2*>(L.uvec + 2);
-            const double2 tq0 = *reinterpret_cast<const double2*>(L.qvec), tq1 = *reinterpret_cast<const double2*>(L.qvec + 2);
-            ColHalves<NPAD, 0>::update(a, uj, qj, l, L.uvec, L.qvec, tu0, tu1, tq0, tq1);
+            static_for<0, KB>([&](auto k) { Q[decltype(k)::value] = L.qvec[decltype(k)::value * 16 + (lane & 15)]; });
+            const double nuj = -uj, nqj = -qj;
+            ColBlocks<NPAD, 0>::update(a, nuj, nqj, l, U, Q);
         }
         TSTAMP(6, a[0]);
         WSYNC();
