@@ -511,40 +511,24 @@ __device__ __forceinline__ void fmac_row_bcast(double& d, const double& rowsrc, 
 }
 template <int NPAD, int B>
 struct ColBlocks {
-    static constexpr int C0 = B * 8, KB = (NPAD + 15) / 16;
-    // p += A[:, 8B..8B+7] * u[8B..8B+7]
+    static constexpr int BS = 4, C0 = B * BS, KB = (NPAD + 15) / 16;
+    // p += A[:, C0..C0+BS-1] * u[C0..C0+BS-1]
     static __device__ __forceinline__ void matvec(const double (&a)[NPAD], const double (&U)[KB], int l,
                                                   double& p0, double& p1) {
         if constexpr (C0 < NPAD) {
             if constexpr (B > 0) {
                 if (C0 > l) return;
             }
-            static_for<0, 8>([&](auto jj) {
+            static_for<0, BS>([&](auto jj) {
                 constexpr int c = C0 + decltype(jj)::value;
                 if constexpr (c < NPAD) fmac_row_bcast<c % 16, (c < 2)>((c & 1) ? p1 : p0, U[c / 16], a[c]);
             });
             ColBlocks<NPAD, B + 1>::matvec(a, U, l, p0, p1);
         }
     }
-    // A[:, c] -= u q_c + q u_c for c = 8B..8B+7; nuj = -u_lane, nqj = -q_lane
-    static __device__ __forceinline__ void update(double (&a)[NPAD], const double& nuj, const double& nqj, int l,
-                                                  const double (&U)[KB], const double (&Q)[KB]) {
-        if constexpr (C0 < NPAD) {
-            if constexpr (B > 0) {
-                if (C0 > l) return;
-            }
-            static_for<0, 8>([&](auto jj) {
-                constexpr int c = C0 + decltype(jj)::value;
-                if constexpr (c < NPAD) fmac_row_bcast<c % 16, (c < 2)>(a[c], Q[c / 16], nuj);
-            });
-            static_for<0, 8>([&](auto jj) {
-                constexpr int c = C0 + decltype(jj)::value;
-                if constexpr (c < NPAD) fmac_row_bcast<c % 16, false>(a[c], U[c / 16], nqj);
-            });
-            ColBlocks<NPAD, B + 1>::update(a, nuj, nqj, l, U, Q);
-        }
-    }
 };
+
+#include "householder_update.inc"
 
 // a[i] for a wave-uniform runtime i in [LO, HI): binary search by uniform branches.  (Publishing
 // the pivot row through LDS instead costs a 16-byte store per column pair for the whole wave and
@@ -652,9 +636,10 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
     uint64_t tlast;
     asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
 #endif
+    // pivot column A[lane][i]: the first one from the bits, the later ones handed back by the update
+    double col = (lane == np - 1) ? (double)cdeg : -(double)((crow >> (np - 1)) & 1ull);
     for (int i = np - 1; i >= 2; --i) {
         const int l = i - 1;
-        double col = column_of<NPAD, 0, NPAD>(a, i);       // A[lane][i] == A[i][lane]
         TSTAMP(0, col);
         const double aii = readlane_d(col, i);
         double uj = (lane <= l) ? col : 0.0;
@@ -689,7 +674,7 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
         {
             static_for<0, KB>([&](auto k) { Q[decltype(k)::value] = L.qvec[decltype(k)::value * 16 + (lane & 15)]; });
             const double nuj = -uj, nqj = -qj;
-            ColBlocks<NPAD, 0>::update(a, nuj, nqj, l, U, Q);
+            HouseholderUpdate<NPAD>::run(a, nuj, nqj, l, U, Q, col);
         }
         TSTAMP(6, a[0]);
         WSYNC();
