@@ -433,6 +433,17 @@ __device__ __forceinline__ double fast_sqrt(double x) {
     e = fma(-hh, s, 0.5);
     return fma(s, e, s);
 }
+// One step only (about 45 bits): enough for the scale factors of a Householder reflector, whose
+// relative error e moves the eigenvalues by about e |A| per step.
+__device__ __forceinline__ double rcp_45(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double sqrt_45(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    const double s = x * r;
+    return fma(s, fma(-0.5 * r, s, 0.5), s);
+}
 
 // Column loops of the register-resident Householder step.  Row j of the matrix lives in
 // the registers a[0..NPAD) of lane j, so every index must be a constant already when the
@@ -509,6 +520,17 @@ __device__ __forceinline__ void fmac_row_bcast(double& d, const double& rowsrc, 
         asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
                      : "+v"(d) : "v"(rowsrc), "v"(m), "n"(I));
 }
+// R[k] of lane t = v of lane 16 k + t % 16: the replicated form the row broadcasts read, by the LDS
+// crossbar (ds_bpermute: no LDS memory, no barrier).
+template <int KB>
+__device__ __forceinline__ void replicate_rows(double v, int lane, double (&R)[KB]) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    static_for<0, KB>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        const int addr = (k * 16 + (lane & 15)) << 2;
+        R[k] = __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, hi), __builtin_amdgcn_ds_bpermute(addr, lo));
+    });
+}
 template <int NPAD, int B>
 struct ColBlocks {
     static constexpr int BS = 4, C0 = B * BS, KB = (NPAD + 15) / 16;
@@ -553,26 +575,25 @@ __device__ __forceinline__ double column_of(const double (&a)[NPAD], int i) {
 template <class LDS>
 __device__ __forceinline__ double sturm_largest_wave(const LDS& L, int np, int lane, double lo, double hi, int rounds) {
     for (int r = 0; r < rounds; ++r) {
-        if (hi - lo <= 2e-12 * hi) break;
+        if (hi - lo <= 1e-11 * hi) break;
         const double w = (hi - lo) * (1.0 / 65.0);
         const double x = lo + w * (double)(lane + 1);
-        // The signs of p_1, p_2, ... are shifted into a 64-bit register (two v_alignbit_b32 per term);
+        // The signs of p_1, p_2, ... are shifted into a 32-bit register (one v_alignbit_b32 per term);
         // with `fresh` new bits at the bottom, the sign changes they add are the set bits
-        // 0..fresh-1 of B ^ (B >> 1) (p_0 = 1 is the zero bit above p_1).  Flushed every 32 terms.
+        // 0..fresh-1 of B ^ (B >> 1) (bit `fresh` is the sign before them; p_0 = 1 is a zero bit).
+        // Flushed before more than 31 are fresh.
         double pm = 1.0, pc = L.de[0].x - x;
-        uint32_t b_hi = 0, b_lo = (uint32_t)__double2hiint(pc) >> 31;
+        uint32_t bits = (uint32_t)__double2hiint(pc) >> 31;
         int cnt = 0, fresh = 1;
         auto term = [&](int i) {
             const double2 t = L.de[i];
             const double pn = fma(t.x - x, pc, -(t.y * pm));
-            b_hi = __builtin_amdgcn_alignbit(b_hi, b_lo, 31);
-            b_lo = __builtin_amdgcn_alignbit(b_lo, (uint32_t)__double2hiint(pn), 31);
+            bits = __builtin_amdgcn_alignbit(bits, (uint32_t)__double2hiint(pn), 31);
             pm = pc;
             pc = pn;
         };
         auto flush = [&]() {
-            const uint64_t B = ((uint64_t)b_hi << 32) | b_lo;
-            cnt += __popcll((B ^ (B >> 1)) & ((1ull << fresh) - 1));
+            cnt += __popc((bits ^ (bits >> 1)) & ((1u << fresh) - 1u));
             fresh = 0;
         };
         int i = 1;
@@ -580,11 +601,14 @@ __device__ __forceinline__ double sturm_largest_wave(const LDS& L, int np, int l
 #pragma unroll
             for (int k = 0; k < 8; ++k) term(i + k);
             fresh += 8;
-            if (fresh >= 32) flush();
-            // keep the recurrence inside the exponent range
-            const int ex = __builtin_amdgcn_frexp_exp(fabs(pc) > fabs(pm) ? pc : pm);
-            pc = ldexp(pc, -ex);
-            pm = ldexp(pm, -ex);
+            if (fresh >= 17) flush();
+            // keep the recurrence inside the exponent range: a term grows or shrinks the pair by at most
+            // |d - x| + e^2 < 2^18 (np <= 208), so every second block of 8 is often enough
+            if (i & 8) {
+                const int ex = __builtin_amdgcn_frexp_exp(fabs(pc) > fabs(pm) ? pc : pm);
+                pc = ldexp(pc, -ex);
+                pm = ldexp(pm, -ex);
+            }
         }
         for (; i < np; ++i) { term(i); ++fresh; }
         flush();
@@ -649,35 +673,30 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
         // h == 0 (row already reduced): u = 0 and 1/h := 0 turn the step into a no-op that still
         // hands the next pivot row over
         const double f = readlane_d(uj, l);
-        const double sq = (h > 0.0) ? fast_sqrt(h) : 0.0;
+        const double sq = (h > 0.0) ? sqrt_45(h) : 0.0;
         const double g = (f >= 0.0) ? -sq : sq;
         const double h2 = h - f * g;
         if (lane == l) uj = f - g;
-        L.uvec[lane] = uj;
-        WSYNC();
         TSTAMP(2, uj);
         // p = A u / h
         double p0 = 0.0, p1 = 0.0;
         double U[KB], Q[KB];
-        static_for<0, KB>([&](auto k) { U[decltype(k)::value] = L.uvec[decltype(k)::value * 16 + (lane & 15)]; });
+        replicate_rows<KB>(uj, lane, U);
         ColBlocks<NPAD, 0>::matvec(a, U, l, p0, p1);
         TSTAMP(3, p0);
-        const double hinv = (h > 0.0) ? fast_rcp(h2) : 0.0;
+        const double hinv = (h > 0.0) ? rcp_45(h2) : 0.0;
         double p = (lane <= l) ? (p0 + p1) * hinv : 0.0;
         TSTAMP(4, p);
         const double K = wave_sum_dpp_upto(uj * p, l) * (0.5 * hinv);
         double qj = fma(-K, uj, p);                         // lanes > l: u = p = 0
         // A -= u q^T + q u^T
-        L.qvec[lane] = qj;
-        WSYNC();
         TSTAMP(5, qj);
         {
-            static_for<0, KB>([&](auto k) { Q[decltype(k)::value] = L.qvec[decltype(k)::value * 16 + (lane & 15)]; });
+            replicate_rows<KB>(qj, lane, Q);
             const double nuj = -uj, nqj = -qj;
             HouseholderUpdate<NPAD>::run(a, nuj, nqj, l, U, Q, col);
         }
         TSTAMP(6, a[0]);
-        WSYNC();
         TSTAMP(7, a[1]);
     }
 #ifdef MARL_EXP_TIMING
