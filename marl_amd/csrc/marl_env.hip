@@ -645,15 +645,30 @@ template <int NPAD, class LDS>
 __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int lane, LDS& L, int rounds) {
     const int cdeg = __popcll(crow);
     int dmax = cdeg;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
+    dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, 0x128, 0xF, 0xF, false));      // row_ror:8, 4, 2, 1
+    dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, 0x124, 0xF, 0xF, false));
+    dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, 0x122, 0xF, 0xF, false));
+    dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, 0x121, 0xF, 0xF, false));
+    dmax = max(max(__builtin_amdgcn_readlane(dmax, 0), __builtin_amdgcn_readlane(dmax, 16)),
+               max(__builtin_amdgcn_readlane(dmax, 32), __builtin_amdgcn_readlane(dmax, 48)));
 
     constexpr int KB = (NPAD + 15) / 16;
     double a[NPAD];                                   // row `lane` of the matrix
-    static_for<0, NPAD>([&](auto k) {
-        constexpr int c = decltype(k)::value;
-        a[c] = (c == lane) ? (double)cdeg : -(double)((crow >> c) & 1ull);
-    });
+    // a[c] = -1 where bit c of the row is set, the degree on the diagonal (c == lane: the select mask is the
+    // constant 1 << c, spelled out because the compiler would build it with a compare per column)
+    {
+        const double dg = (double)cdeg;
+        const int dg_hi = __double2hiint(dg), dg_lo = __double2loint(dg);
+        const uint32_t w_lo = (uint32_t)crow, w_hi = (uint32_t)(crow >> 32);
+        static_for<0, NPAD>([&](auto k) {
+            constexpr int c = decltype(k)::value;
+            int hi = __builtin_amdgcn_sbfe((int)(c < 32 ? w_lo : w_hi), c & 31, 1) & (int)0xBFF00000, lo;
+            const uint64_t diag = 1ull << c;
+            asm("v_cndmask_b32_e64 %0, %0, %2, %4\n\tv_cndmask_b32_e64 %1, 0, %3, %4"
+                : "+v"(hi), "=v"(lo) : "v"(dg_hi), "v"(dg_lo), "s"(diag));
+            a[c] = __hiloint2double(hi, lo);
+        });
+    }
 
 #ifdef MARL_EXP_TIMING
     double tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -665,11 +680,11 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
     for (int i = np - 1; i >= 2; --i) {
         const int l = i - 1;
         TSTAMP(0, col);
-        const double aii = readlane_d(col, i);
+        const double aii = col;                            // meaningful in lane i: A[i][i]
         double uj = (lane <= l) ? col : 0.0;
         double h = wave_sum_dpp_upto(uj * uj, l);
         TSTAMP(1, h);
-        if (lane == 0) L.de[i] = make_double2(aii, h);
+        if (lane == i) L.de[i] = make_double2(aii, h);
         // h == 0 (row already reduced): u = 0 and 1/h := 0 turn the step into a no-op that still
         // hands the next pivot row over
         const double f = readlane_d(uj, l);
