@@ -245,11 +245,10 @@ struct WaveLds {
     int asg[WAVE];
     int jb[WAVE];
     // eigen-solver only (kernels that do not solve allocate the struct up to here: front_lds_bytes)
-    __attribute__((aligned(16))) double uvec[WAVE], qvec[WAVE];   // Householder vectors u, q
     double2 de[WAVE];                 // tridiagonal: (diagonal, squared off-diagonal) per row
 };
 
-inline size_t front_lds_bytes() { return offsetof(WaveLds, uvec); }
+inline size_t front_lds_bytes() { return offsetof(WaveLds, de); }
 inline size_t wave_lds_bytes(int) { return sizeof(WaveLds); }
 
 // ------------------------------------------------------------------ pairwise bit rows
@@ -1095,9 +1094,14 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
     const int tick = S.tick[e] + 1;
     int num = S.n_clusters[e], ncent = S.ncent[e];
     const double lam0 = S.lambda2_initial[e];
-    const size_t oc = (size_t)e * KS + (lane < KS ? lane : KS - 1);
-    const double ccx = S.cent_x[oc], ccy = S.cent_y[oc];
-    const int ccs = S.cent_size[oc];
+    // the cluster table is read up to its fill level only (the level arrives with the first loads; the
+    // table is not needed before the enemy dynamics are done)
+    double ccx = 0.0, ccy = 0.0;
+    int ccs = 0;
+    if (lane < ncent) {
+        const size_t oc = (size_t)e * KS + lane;
+        ccx = S.cent_x[oc]; ccy = S.cent_y[oc]; ccs = S.cent_size[oc];
+    }
 
     // -- action decode (jammer_env.py:372-388, action_space.py:190-240)
     float raw_vx = 0.0f, raw_vy = 0.0f;
@@ -1262,7 +1266,6 @@ __global__ __launch_bounds__(1024) void solve_order_kernel(int E, MarlEnvState S
 }
 
 struct SolveLds {
-    __attribute__((aligned(16))) double uvec[WAVE], qvec[WAVE];
     double2 de[WAVE];
 };
 
