@@ -2333,12 +2333,68 @@ __global__ __launch_bounds__(WAVE) void pair_bits_big_kernel(MarlEnvParams P, co
 }
 
 // ------------------------------------------------------------------ team solver (64 < n' <= 208)
-// One workgroup of 512 threads per eigenproblem, the matrix in registers: row r belongs to the
-// threads 2r and 2r+1 (neighbouring lanes), thread 2r+h holding the columns of parity h, column
-// c = 2k+h in a[k].  The Householder step is the one of mu_max_compact_wave: the column loops are
-// the same ColHalves templates over the local columns k <= l/2, u and q are published in LDS split by
-// column parity, the two half-row products meet by one DPP swap, and the sums over the rows go
-// through a wave sum plus one LDS word per wave.
+// One workgroup of 512 threads per eigenproblem, the matrix in registers: row r belongs to two
+// threads 16 lanes apart (a wave holds 32 rows: lanes 0..15 and 32..47 the columns of parity 0 of rows
+// 0..15 and 16..31, lanes 16..31 and 48..63 those of parity 1), column c = 2k+h in a[k] of the thread of
+// parity h.  The Householder step is the one of mu_max_compact_wave: u and p are published in LDS split
+// by column parity and reach the multiply-adds by row_newbcast (TeamCols), the two half-row products
+// meet by one lane swap, and the sums over the rows go through a wave sum plus one LDS word per wave.
+// Column loops of the team solver: a[k] is the thread's k-th local column.  u (and p) of the thread's
+// column parity sit in LDS; a chunk of 16 of them is read into one register (lane t: entry
+// 16 q + t % 16) and handed to the 16 multiply-adds of the chunk by row_newbcast, the next chunk being
+// read while this one is used.  Every lane of a row of 16 must want the same column: the two threads
+// of a matrix row are therefore 16 lanes apart (see mu_max_team), not neighbours.
+template <int CH, int B>
+struct TeamCols {
+    static constexpr int C0 = B * 4;
+    static __device__ __forceinline__ void matvec(const double (&a)[CH], const double* u16, int lh, double& p0,
+                                                  double& p1, double cur, double nxt) {
+        if constexpr (C0 < CH) {
+            if constexpr (B > 0) {
+                if (C0 > lh) return;
+            }
+            if constexpr (C0 % 16 == 0) {
+                if constexpr (B > 0) cur = nxt;
+                if constexpr (C0 + 16 < CH) nxt = u16[C0 + 16];
+            }
+            static_for<0, 4>([&](auto jj) {
+                constexpr int c = C0 + decltype(jj)::value;
+                if constexpr (c < CH) fmac_row_bcast<c % 16, (c % 16 < 2)>((c & 1) ? p1 : p0, cur, a[c]);
+            });
+            TeamCols<CH, B + 1>::matvec(a, u16, lh, p0, p1, cur, nxt);
+        }
+    }
+    // a[c] += nu * p_c + nw * u_c  (nu = -u_row, nw = -w_row)
+    static __device__ __forceinline__ void update(double (&a)[CH], const double& nu, const double& nw, int lh,
+                                                  const double* u16, const double* p16, double cu, double nu16,
+                                                  double cp, double np16) {
+        if constexpr (C0 < CH) {
+            if constexpr (B > 0) {
+                if (C0 > lh) return;
+            }
+            if constexpr (C0 % 16 == 0) {
+                if constexpr (B > 0) { cu = nu16; cp = np16; }
+                if constexpr (C0 + 16 < CH) { nu16 = u16[C0 + 16]; np16 = p16[C0 + 16]; }
+            }
+            static_for<0, 4>([&](auto jj) {
+                constexpr int c = C0 + decltype(jj)::value;
+                if constexpr (c < CH) fmac_row_bcast<c % 16, (c % 16 < 2)>(a[c], cp, nu);
+            });
+            static_for<0, 4>([&](auto jj) {
+                constexpr int c = C0 + decltype(jj)::value;
+                if constexpr (c < CH) fmac_row_bcast<c % 16, false>(a[c], cu, nw);
+            });
+            TeamCols<CH, B + 1>::update(a, nu, nw, lh, u16, p16, cu, nu16, cp, np16);
+        }
+    }
+};
+// The value of the lane 16 away inside the same half wave (ds_swizzle, bit mode: lane ^ 16).
+__device__ __forceinline__ double swap16(double v) {
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
+    return __hiloint2double(hi, lo);
+}
+
 constexpr int TEAM_THREADS = 512;
 constexpr int TEAM_WAVES = TEAM_THREADS / WAVE;
 constexpr int TEAM_ROWS = TEAM_THREADS / 2;
@@ -2357,7 +2413,7 @@ struct TeamLds {
 template <int CH, int S>
 __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, int np, TeamLds<CH>& L, int rounds) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & (WAVE - 1);
-    const int r = tid >> 1, h = tid & 1;
+    const int r = wave * 32 + ((lane >> 5) << 4) + (lane & 15), h = (lane >> 4) & 1;
     unsigned long long cw[S];
     int cdeg = 0;
 #pragma unroll
@@ -2394,7 +2450,7 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
         const int l = i - 1, lh = l >> 1;
         double mine = column_of<CH, 0, CH>(a, i >> 1);
         TSTAMP(0, mine);
-        const double other = dpp_mov<0xB1>(mine);                   // quad_perm [1,0,3,2]: the partner's value
+        const double other = swap16(mine);                          // the partner's value
         const double v = (h == (i & 1)) ? mine : other;             // A[r][i]
         double uj = (r <= l) ? v : 0.0;
         const double hw = wave_sum_dpp(h == 0 ? uj * uj : 0.0);
@@ -2417,14 +2473,12 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
         TSTAMP(3, uj);
         __syncthreads();
         double p0 = 0.0, p1 = 0.0;
-        {
-            const double* uv = L.uh[h];
-            const double2 t0 = *reinterpret_cast<const double2*>(uv), t1 = *reinterpret_cast<const double2*>(uv + 2);
-            ColHalves<CH, 0>::matvec(a, uv, lh, p0, p1, t0, t1);
-        }
+        const double* u16 = L.uh[h] + (lane & 15);
+        const double u0 = u16[0];
+        TeamCols<CH, 0>::matvec(a, u16, lh, p0, p1, u0, u0);
         TSTAMP(4, p0);
         const double ps = p0 + p1;
-        const double pr = ps + dpp_mov<0xB1>(ps);
+        const double pr = ps + swap16(ps);
         const double p = (r <= l) ? pr * hinv : 0.0;
         const double kw = wave_sum_dpp(h == 0 ? uj * p : 0.0);
         if (h == 0) L.qh[r & 1][r >> 1] = p;
@@ -2436,11 +2490,10 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
         for (int k = 0; k < TEAM_WAVES; ++k) ksum += L.red[1][k];
         const double wj = fma(-(ksum * hinv), uj, p);                 // p - 2K u,  K = ksum hinv / 2
         {
-            const double* uv = L.uh[h];
-            const double* pv = L.qh[h];
-            const double2 tu0 = *reinterpret_cast<const double2*>(uv), tu1 = *reinterpret_cast<const double2*>(uv + 2);
-            const double2 tp0 = *reinterpret_cast<const double2*>(pv), tp1 = *reinterpret_cast<const double2*>(pv + 2);
-            ColHalves<CH, 0>::update(a, uj, wj, lh, uv, pv, tu0, tu1, tp0, tp1);
+            const double* p16 = L.qh[h] + (lane & 15);
+            const double pq0 = p16[0];
+            const double nuj = -uj, nwj = -wj;
+            TeamCols<CH, 0>::update(a, nuj, nwj, lh, u16, p16, u0, u0, pq0, pq0);
         }
         TSTAMP(6, a[0]);
     }
@@ -2452,9 +2505,9 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
     }
 #endif
     // the remaining 2 x 2 block: A[1][1] is column 1 (parity 1, k = 0) of row 1, A[1][0] and A[0][0] are a[0]
-    if (tid == 3) L.colbuf[2] = a[0];
-    if (tid == 2) L.colbuf[1] = a[0];
-    if (tid == 0) L.colbuf[0] = a[0];
+    if (r == 1 && h == 1) L.colbuf[2] = a[0];
+    if (r == 1 && h == 0) L.colbuf[1] = a[0];
+    if (r == 0 && h == 0) L.colbuf[0] = a[0];
     __syncthreads();
     if (tid == 0) {
         L.de[1] = make_double2(L.colbuf[2], L.colbuf[1] * L.colbuf[1]);
