@@ -448,63 +448,10 @@ __device__ __forceinline__ double sqrt_45(double x) {
 // the registers a[0..NPAD) of lane j, so every index must be a constant already when the
 // code is parsed (a loop variable, even of a fully unrollable loop, makes the compiler
 // keep the array in scratch memory): loops are expanded by template recursion, in blocks
-// of 8 columns with a wave-uniform exit after the block that holds column l.  Columns
+// of a few columns with a wave-uniform exit after the block that holds column l.  Columns
 // l+1.. of the last block are no-ops because u and q are zero there.
-
-// The broadcasts of u and q come from LDS as 16-byte reads of two neighbouring columns; the
-// reads of the next half block (4 columns) are issued before the arithmetic of the current one.
-// H counts half blocks; the exit test sits at every second one (never at the first: l >= 1).
-template <int NPAD, int H>
-struct ColHalves {
-    static constexpr int C0 = H * 4;
-    // p += A[:, 4H..4H+3] * v[4H..4H+3]; t = (v_4H, v_4H+1), (v_4H+2, v_4H+3) already loaded
-    static __device__ __forceinline__ void matvec(const double (&a)[NPAD], const double* uvec, int l,
-                                                  double& p0, double& p1, double2 t0, double2 t1) {
-        if constexpr (C0 < NPAD) {
-            if constexpr (H % 2 == 0 && H > 0) {
-                if (C0 > l) return;
-            }
-            double2 n0 = t0, n1 = t1;
-            if constexpr (C0 + 4 < NPAD) {
-                n0 = *reinterpret_cast<const double2*>(uvec + C0 + 4);
-                n1 = *reinterpret_cast<const double2*>(uvec + C0 + 6);
-            }
-            p0 = fma(a[C0], t0.x, p0);
-            p1 = fma(a[C0 + 1], t0.y, p1);
-            p0 = fma(a[C0 + 2], t1.x, p0);
-            p1 = fma(a[C0 + 3], t1.y, p1);
-            // pin the partial sums here: keeps the following reads behind the exit test
-            asm volatile("" : "+v"(p0), "+v"(p1) :: "memory");
-            ColHalves<NPAD, H + 1>::matvec(a, uvec, l, p0, p1, n0, n1);
-        }
-    }
-    // A[:, c] -= u q_c + q u_c for c = 4H..4H+3; tu / tq = the u and q pairs of this half block
-    static __device__ __forceinline__ void update(double (&a)[NPAD], double uj, double qj, int l, const double* uvec,
-                                                  const double* qvec, double2 tu0, double2 tu1, double2 tq0, double2 tq1) {
-        if constexpr (C0 < NPAD) {
-            if constexpr (H % 2 == 0 && H > 0) {
-                if (C0 > l) return;
-            }
-            double2 nu0 = tu0, nu1 = tu1, nq0 = tq0, nq1 = tq1;
-            if constexpr (C0 + 4 < NPAD) {
-                nu0 = *reinterpret_cast<const double2*>(uvec + C0 + 4);
-                nq0 = *reinterpret_cast<const double2*>(qvec + C0 + 4);
-                nu1 = *reinterpret_cast<const double2*>(uvec + C0 + 6);
-                nq1 = *reinterpret_cast<const double2*>(qvec + C0 + 6);
-            }
-            a[C0] = fma(-uj, tq0.x, fma(-qj, tu0.x, a[C0]));
-            a[C0 + 1] = fma(-uj, tq0.y, fma(-qj, tu0.y, a[C0 + 1]));
-            a[C0 + 2] = fma(-uj, tq1.x, fma(-qj, tu1.x, a[C0 + 2]));
-            a[C0 + 3] = fma(-uj, tq1.y, fma(-qj, tu1.y, a[C0 + 3]));
-            // pin this half block's results here: without it the compiler issues every read first
-            // and sinks all the arithmetic behind them, which needs 4 registers per column
-            asm volatile("" : "+v"(a[C0]), "+v"(a[C0 + 1]), "+v"(a[C0 + 2]), "+v"(a[C0 + 3]) :: "memory");
-            ColHalves<NPAD, H + 1>::update(a, uj, qj, l, uvec, qvec, nu0, nu1, nq0, nq1);
-        }
-    }
-};
-
-// The same column loops with the broadcasts taken from registers instead of LDS.  u (and q) are held
+//
+// The broadcasts of u and q come from registers, not from LDS.  u (and q) are held
 // replicated, U[k] of lane t = u[16 k + t % 16], so that column c = 16 k + i is lane i of every row of
 // 16 lanes of U[k]: the DPP control row_newbcast:i of v_fmac_f64_dpp hands exactly that to all
 // lanes, inside the multiply-add.  One VALU instruction per column and term, no LDS read.
@@ -551,9 +498,9 @@ struct ColBlocks {
 
 #include "householder_update.inc"
 
-// a[i] for a wave-uniform runtime i in [LO, HI): binary search by uniform branches.  (Publishing
-// the pivot row through LDS instead costs a 16-byte store per column pair for the whole wave and
-// made the LDS pipe the bottleneck.)
+// a[i] for a wave-uniform runtime i in [LO, HI): binary search by uniform branches (team solver; the
+// wave solver has the pivot column handed back by its update).  Publishing the pivot row through LDS
+// instead costs a 16-byte store per column pair for the whole wave, whatever the execution mask.
 template <int NPAD, int LO, int HI>
 __device__ __forceinline__ double column_of(const double (&a)[NPAD], int i) {
     if constexpr (HI - LO == 1) {

@@ -157,6 +157,28 @@ def test_lambda2_accuracy_with_more_rounds():
     assert np.max(np.abs(got - np.array(want))) < 1e-9
 
 
+def test_lambda2_every_matrix_width():
+    """Every matrix width of the register solver and every position of the last column inside a block of
+    the unrolled column loops: n = 2..64, random graphs of several densities (most of them connected and
+    with no vertex of full degree, so that the eigenproblem has n rows), against LAPACK."""
+    lib = _lib.load()
+    rng = np.random.RandomState(11)
+    sizes = list(range(2, 65)) + [65, 66, 80, 96, 97, 112, 127, 128, 129, 130, 144, 160, 176, 192, 200, 207, 208,
+                                  209, 224, 256]       # beyond 64: team solver (two widths) and workspace solver
+    for n in sizes:
+        mats, want = [], []
+        for dens in (0.15, 0.3, 0.45, 0.6, 0.75, 0.9, 0.97):
+            for _ in range(3 if n <= 64 else 1):
+                A = np.triu(rng.rand(n, n) < dens, 1)
+                A = A | A.T
+                mats.append(orc.pack_rows(A).view(np.int32))
+                want.append(orc.lambda2_of_laplacian(orc.laplacian(A)))
+        bits = dev(np.stack(mats), torch.int32)
+        got = lambda2_bits(n, len(mats), bits).cpu().numpy()
+        want = np.array(want)
+        assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 2e-9, (n, got, want)
+
+
 def test_dbscan_edge_vectors():
     lib = _lib.load()
     z = gu.load("edges.npz")
