@@ -168,6 +168,13 @@ class BatchedJammerEnv:
             self.jam_bits = torch.zeros(self.E, self.N, W, dtype=torch.int32, device=self.device) if debug_bits else None
             self._terminated = torch.zeros(self.E, dtype=torch.bool, device=self.device)
         self._episode = 0
+        # Host-side bounds on the envs' step counters (min, max); None = unknown.  While the largest
+        # counter cannot have reached max_steps no env is truncated and the masked auto-reset launch is
+        # left out.  Known only while every state change goes through this object's eager calls: a HIP
+        # graph replays launches without running this code, so the first call under stream capture
+        # turns the bookkeeping off for good.
+        self._count_bounds: Optional[list] = None
+        self._track_counts = True
 
     # -- reset ---------------------------------------------------------------
     def reset(self, seed: Optional[int] = None, mask: Optional[torch.Tensor] = None, *,
@@ -206,6 +213,10 @@ class BatchedJammerEnv:
             _lib.check(self.lib.marl_env_reset(C.byref(self.params), C.byref(self.state), C.byref(io), _stream()),
                        "marl_env_reset")
         self._keepalive = keep
+        if mask is None:
+            self._count_bounds = [0, 0]
+        elif self._count_bounds is not None:
+            self._count_bounds[0] = 0
         v = self.views
         info = dict(lambda2_initial=v["lambda2_initial"], lambda2_current=v["lambda2_initial"],
                     enemy_band=v["enemy_band"], n_clusters=v["n_clusters"], step=v["step_count"])
@@ -247,9 +258,23 @@ class BatchedJammerEnv:
         if self.avg_power is not None:
             info["avg_jamming_power_dbm"] = self.avg_power
         truncated = trunc.view(torch.bool) if trunc.dtype == torch.uint8 else trunc
-        if self.auto_reset:
+        if self._track_counts and torch.cuda.is_current_stream_capturing():
+            self._track_counts, self._count_bounds = False, None
+        b = self._count_bounds if self._track_counts else None
+        if b is not None:
+            b[0] += 1
+            b[1] += 1
+        if self.auto_reset and b is not None and b[1] < self.cfg.max_steps:
+            # no env can be truncated yet: nothing to reset, the episode values are the current ones
+            info["episode_lambda2_initial"] = v["lambda2_initial"]
+            info["episode_step"] = v["step_count"]
+            self._episode += 1            # the draws of a later reset do not depend on the launches left out
+        elif self.auto_reset:
             info["episode_lambda2_initial"] = v["lambda2_initial"].clone()
             info["episode_step"] = v["step_count"].clone()
+            if b is not None:
+                # envs at max_steps start over; if even the smallest counter is there, all of them do
+                self._count_bounds = [0, 0] if b[0] >= self.cfg.max_steps else [0, self.cfg.max_steps - 1]
             rio = MarlResetIO()
             rio.mask = trunc.data_ptr()
             rio.obs = obs.data_ptr()

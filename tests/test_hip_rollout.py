@@ -85,3 +85,34 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and "cpu_baseline" not in d
     assert d["value"] > 0 and abs(d["value"] - 2 * 512 * 20 / (d["ms_per_step"] * 20e-3)) / d["value"] < 1e-6
+
+
+def test_auto_reset_launch_is_skipped_only_when_nothing_can_be_done():
+    """The masked auto-reset launch is left out while no step counter can have reached max_steps (host-side
+    bounds).  An env that keeps the bounds and one that always launches must stay identical, also after
+    single envs were reset out of lockstep."""
+    E, T = 64, 7
+    cfg = EnvConfig.fast_preset(N=12, M=3, max_steps=T)
+    a = BatchedJammerEnv(E, cfg, seed=5, auto_reset=True)
+    b = BatchedJammerEnv(E, cfg, seed=5, auto_reset=True)
+    b._track_counts = False
+    a.reset()
+    b.reset()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    for t in range(40):
+        act = torch.empty(E, 3, 3, device="cuda")
+        act[..., :2] = (torch.rand(E, 3, 2, device="cuda", generator=g) * 2 - 1) * 5
+        act[..., 2] = torch.randint(0, 4, (E, 3), device="cuda", generator=g).float()
+        oa, ra, _, ta, ia = a.step(act)
+        ob, rb, _, tb, ib = b.step(act)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(ta, tb), t
+        assert torch.equal(a.views["step_count"], b.views["step_count"]), t
+        assert torch.equal(ia["episode_step"], ib["episode_step"]), t
+        assert int(a.views["step_count"].max()) < T
+        if t in (3, 17):                      # some envs start over early: the others must still truncate on time
+            m = torch.zeros(E, dtype=torch.bool, device="cuda")
+            m[t::5] = True
+            a.reset(mask=m)
+            b.reset(mask=m)
+    assert a._count_bounds == [0, T - 1]          # out of lockstep: the launch stays in from then on
