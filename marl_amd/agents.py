@@ -23,6 +23,51 @@ from torch.distributions import Categorical, Normal
 from . import _lib
 
 
+def _split_k(rows: int) -> int:
+    """Number of row chunks for the weight gradient of a tall batch: a power of two <= 64 that divides
+    `rows` and leaves chunks of at least 256 rows (1 = no split)."""
+    s = 64
+    while s > 1 and (rows % s or rows // s < 256):
+        s //= 2
+    return s
+
+
+class _TallLinearFn(torch.autograd.Function):
+    """y = x W^T + b for x [B, in] with B in the tens of thousands.  The weight gradient dY^T X is a GEMM
+    with a 128 x 128 (or smaller) result and K = B: left to the library as one call it runs on a handful
+    of workgroups (100 us at B = 32 768, half of the PPO update's time).  It is issued as a batched GEMM
+    over row chunks instead and the partial results are summed: the same arithmetic on all CUs."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        rows = x.shape[0]
+        gx = gy @ w if ctx.needs_input_grad[0] else None
+        s = _split_k(rows)
+        if s > 1:
+            gyc, xc = gy.view(s, rows // s, gy.shape[1]), x.view(s, rows // s, x.shape[1])
+            gw = torch.bmm(gyc.transpose(1, 2), xc).sum(0)
+        else:
+            gw = gy.t() @ x
+        return gx, gw, gy.sum(0)
+
+
+class TallLinear(nn.Linear):
+    """nn.Linear (same parameters, same state-dict keys) whose backward splits the weight-gradient GEMM
+    over row chunks when the batch is tall."""
+
+    def forward(self, x):
+        if x.dim() == 2 and x.is_cuda and x.is_contiguous() and torch.is_grad_enabled() and _split_k(x.shape[0]) > 1:
+            return _TallLinearFn.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 class Actor(nn.Module):
     """agents/actor.py:56-247: 5 -> hidden -> hidden (LayerNorm + ReLU) trunk, heads for
     velocity mean (2), clamped log-std (2) and band logits (num_bands)."""
@@ -31,11 +76,11 @@ class Actor(nn.Module):
         super().__init__()
         self.obs_dim, self.hidden_dim, self.v_max, self.num_bands = obs_dim, hidden_dim, v_max, num_bands
         self.log_std_min, self.log_std_max = log_std_min, log_std_max
-        self.trunk = nn.Sequential(nn.Linear(obs_dim, hidden_dim), nn.LayerNorm(hidden_dim), nn.ReLU(),
-                                   nn.Linear(hidden_dim, hidden_dim), nn.LayerNorm(hidden_dim), nn.ReLU())
-        self.mu_head = nn.Linear(hidden_dim, 2)
-        self.log_std_head = nn.Linear(hidden_dim, 2)
-        self.band_head = nn.Linear(hidden_dim, num_bands)
+        self.trunk = nn.Sequential(TallLinear(obs_dim, hidden_dim), nn.LayerNorm(hidden_dim), nn.ReLU(),
+                                   TallLinear(hidden_dim, hidden_dim), nn.LayerNorm(hidden_dim), nn.ReLU())
+        self.mu_head = TallLinear(hidden_dim, 2)
+        self.log_std_head = TallLinear(hidden_dim, 2)
+        self.band_head = TallLinear(hidden_dim, num_bands)
         for m in self.modules():                                    # actor.py:105-116
             if isinstance(m, nn.Linear):
                 nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
@@ -87,8 +132,8 @@ class Critic(nn.Module):
     def __init__(self, obs_dim=5, hidden_dim=128):
         super().__init__()
         self.obs_dim, self.hidden_dim = obs_dim, hidden_dim
-        self.network = nn.Sequential(nn.Linear(obs_dim, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, hidden_dim),
-                                     nn.ReLU(), nn.Linear(hidden_dim, 1))
+        self.network = nn.Sequential(TallLinear(obs_dim, hidden_dim), nn.ReLU(), TallLinear(hidden_dim, hidden_dim),
+                                     nn.ReLU(), TallLinear(hidden_dim, 1))
         for m in self.modules():
             if isinstance(m, nn.Linear):
                 nn.init.orthogonal_(m.weight, gain=np.sqrt(2))

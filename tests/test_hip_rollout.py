@@ -116,3 +116,26 @@ def test_auto_reset_launch_is_skipped_only_when_nothing_can_be_done():
             a.reset(mask=m)
             b.reset(mask=m)
     assert a._count_bounds == [0, T - 1]          # out of lockstep: the launch stays in from then on
+
+
+@pytest.mark.parametrize("fin,fout", [(5, 128), (128, 128), (128, 4), (128, 1)])
+def test_tall_linear_gradients_match_nn_linear(fin, fout):
+    """TallLinear splits the weight-gradient GEMM over row chunks: same values as nn.Linear."""
+    from marl_amd.agents import TallLinear, _split_k
+    rows = 32768
+    assert _split_k(rows) == 64 and _split_k(1000) == 2 and _split_k(300) == 1 and _split_k(2048) == 8
+    torch.manual_seed(0)
+    a = TallLinear(fin, fout).cuda()
+    b = torch.nn.Linear(fin, fout).cuda()
+    b.load_state_dict(a.state_dict())
+    x1 = torch.randn(rows, fin, device="cuda", requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    g = torch.randn(rows, fout, device="cuda")
+    y1, y2 = a(x1), b(x2)
+    y1.backward(g)
+    y2.backward(g)
+    assert torch.allclose(y1, y2, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(x1.grad, x2.grad, rtol=1e-5, atol=1e-5)
+    scale = float(b.weight.grad.abs().max())
+    assert float((a.weight.grad - b.weight.grad).abs().max()) <= 2e-5 * scale
+    assert float((a.bias.grad - b.bias.grad).abs().max()) <= 2e-5 * float(b.bias.grad.abs().max())
