@@ -2631,11 +2631,14 @@ size_t workspace_bytes(int N, int E) {
         default: hipLaunchKernelGGL((kern<4>), grid, dim3(WAVE), sizeof(BigLds<4>), (hipStream_t)(stream), __VA_ARGS__); break; \
     }
 
-// The wave kernels are instantiated per register-matrix width NPAD = N rounded up to 8.
+// The wave kernels are instantiated per register-matrix width NPAD = N rounded up to 8, and for 50 (the
+// reference's standard swarm: 12 registers fewer than 56 make room for a fourth wave per SIMD).
 #define MARL_LAUNCH_NPAD(NP, kern, grid, lds, stream, ...) \
     hipLaunchKernelGGL((kern<NP>), grid, dim3(WAVE), lds, (hipStream_t)(stream), __VA_ARGS__)
 #define MARL_DISPATCH_NPAD(N, kern, grid, lds, stream, ...)                                   \
-    switch (((N) + 7) / 8) {                                                                   \
+    if ((N) > 48 && (N) <= 50) {                                                               \
+        MARL_LAUNCH_NPAD(50, kern, grid, lds, stream, __VA_ARGS__);                            \
+    } else switch (((N) + 7) / 8) {                                                            \
         case 1: MARL_LAUNCH_NPAD(8, kern, grid, lds, stream, __VA_ARGS__); break;              \
         case 2: MARL_LAUNCH_NPAD(16, kern, grid, lds, stream, __VA_ARGS__); break;             \
         case 3: MARL_LAUNCH_NPAD(24, kern, grid, lds, stream, __VA_ARGS__); break;             \
