@@ -733,11 +733,13 @@ def test_state_buffer_need_not_be_zeroed_before_the_first_full_reset():
         assert torch.equal(ia["lambda2_current"], ib["lambda2_current"])
 
 
-def test_split_schedule_equals_fused_schedule_over_episodes():
+def test_split_schedules_equal_fused_schedule_over_episodes():
     """The three-launch step (histogram, counting sort, longest-first solves, hand-over buffers) must give
-    bit for bit what the one-launch step gives: 4 096 envs, 130 steps across two auto-resets."""
-    E, N, M = 4096, 50, 8
-    envs = [BatchedJammerEnv(E, EnvConfig.fast_preset(N=N, M=M, max_steps=60, step_schedule=s), seed=21)
+    bit for bit what the one-launch step gives: 4 097 envs, 130 steps across two auto-resets, with the
+    optional outputs."""
+    E, N, M = 4097, 50, 8
+    envs = [BatchedJammerEnv(E, EnvConfig.fast_preset(N=N, M=M, max_steps=60, step_schedule=s), seed=21,
+                             track_avg_power=True, debug_bits=True)
             for s in ("fused", "split")]
     for env in envs:
         env.reset()
@@ -746,12 +748,17 @@ def test_split_schedule_equals_fused_schedule_over_episodes():
         act = (torch.rand(E, M, 3, device="cuda", generator=g) - 0.5) * 11
         act[:, :, 2] = torch.randint(0, 4, (E, M), device="cuda", generator=g).float()
         outs = [env.step(act) for env in envs]
-        (of, rf, _, tf, inf_), (os_, rs, _, ts, ins) = outs
-        assert torch.equal(of, os_) and torch.equal(rf, rs) and torch.equal(tf, ts), t
-        assert torch.equal(inf_["lambda2_current"], ins["lambda2_current"]), t
-        assert torch.equal(inf_["reward_terms"], ins["reward_terms"]), t
-    assert torch.equal(envs[0].views["enemy_x"], envs[1].views["enemy_x"])
-    assert int(envs[1].views["tick"].min()) == 130
+        of, rf, _, tf, inf_ = outs[0]
+        for os_, rs, _, ts, ins in outs[1:]:
+            assert torch.equal(of, os_) and torch.equal(rf, rs) and torch.equal(tf, ts), t
+            assert torch.equal(inf_["lambda2_current"], ins["lambda2_current"]), t
+            assert torch.equal(inf_["reward_terms"], ins["reward_terms"]), t
+            assert torch.equal(inf_["avg_jamming_power_dbm"], ins["avg_jamming_power_dbm"]), t
+        assert torch.equal(envs[0].adj_bits, envs[1].adj_bits) and torch.equal(envs[0].jam_bits, envs[1].jam_bits), t
+    for env in envs[1:]:
+        assert torch.equal(envs[0].views["enemy_x"], env.views["enemy_x"])
+        assert torch.equal(envs[0].views["labels"], env.views["labels"])
+        assert int(env.views["tick"].min()) == 130
 
 
 def test_reward_per_agent_matches_reference_vectors():
