@@ -56,7 +56,8 @@ enum {
     MARL_OK = 0,
     MARL_EINVAL = -1,           /* bad argument (null pointer, size out of range) */
     MARL_EUNSUPPORTED = -2,     /* N or M beyond what the kernels support */
-    MARL_EHIP = -3              /* a HIP runtime call failed; see marl_last_hip_error */
+    MARL_EHIP = -3,             /* a HIP runtime call failed; see marl_last_hip_error */
+    MARL_ETOOBIG = -4           /* marl_lambda2_from_bits_static: more scratch needed than the static buffer holds */
 };
 
 /* Constructor arguments of JammerEnv (environment/jammer_env.py:94-127) with the
@@ -205,6 +206,18 @@ int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t *bits, double *l
 /* Bytes of device scratch marl_lambda2_from_bits needs (0 for N <= 64; the matrix of the
  * eigenproblem otherwise).  marl_state_bytes already includes the same amount for the step. */
 size_t marl_lambda2_workspace_bytes(int32_t N, int32_t E);
+
+/* The same as marl_lambda2_from_bits without a workspace argument and without any allocation.  It has no
+ * counterpart in the reference: it exists for callers that cannot call hipMalloc (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid allocation).  The scratch the solver needs for
+ * N > 64 is a static device array of MARL_STATIC_SCRATCH_BYTES inside the library (one copy per GPU, held
+ * until the process ends); a request with marl_lambda2_workspace_bytes(N, E) beyond that returns
+ * MARL_ETOOBIG (32 MiB holds e.g. 104 envs at N = 200, 64 at N = 256; any E at N <= 64, which needs none).
+ * The first call on a device looks the array's address up (make that call outside graph capture).  All
+ * calls on one GPU share the array: calls that overlap in time on one GPU (different streams) race. */
+#define MARL_STATIC_SCRATCH_BYTES (32u << 20)
+int marl_lambda2_from_bits_static(int32_t N, int32_t E, const uint32_t *bits, double *lambda2,
+                                  int32_t rounds, void *stream);
 
 /* DBSCANClusterer.fit + get_cluster_sizes (clustering/dbscan_clustering.py:78-144)
  * -> labels [E][N], cent_x/cent_y/cent_size [E][N+1], n_clusters/ncent [E]. */

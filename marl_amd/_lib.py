@@ -18,7 +18,8 @@ MAX_M = 64
 ENEMY_RANDOM_WALK, ENEMY_COORDINATED_TURN = 0, 1
 SCHEDULE_AUTO, SCHEDULE_FUSED, SCHEDULE_SPLIT = 0, 1, 2
 
-MARL_OK, MARL_EINVAL, MARL_EUNSUPPORTED, MARL_EHIP = 0, -1, -2, -3
+MARL_OK, MARL_EINVAL, MARL_EUNSUPPORTED, MARL_EHIP, MARL_ETOOBIG = 0, -1, -2, -3, -4
+STATIC_SCRATCH_BYTES = 32 << 20
 
 _pd, _pf, _pi, _pu8, _pu32 = (C.c_void_p,) * 5   # device pointers travel as integers
 
@@ -84,6 +85,7 @@ SYMBOLS = {
     "marl_jam_mask_bits": (C.c_int, [C.POINTER(MarlEnvParams), C.c_int32, _pd, _pd, _pi, _pd, _pd, _pi, _pu32,
                                      C.c_void_p]),
     "marl_lambda2_from_bits": (C.c_int, [C.c_int32, C.c_int32, _pu32, _pd, C.c_int32, C.c_void_p, C.c_void_p]),
+    "marl_lambda2_from_bits_static": (C.c_int, [C.c_int32, C.c_int32, _pu32, _pd, C.c_int32, C.c_void_p]),
     "marl_lambda2_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "marl_dbscan": (C.c_int, [C.POINTER(MarlEnvParams), C.c_int32, _pd, _pd, _pi, _pd, _pd, _pi, _pi, _pi,
                               C.c_void_p]),

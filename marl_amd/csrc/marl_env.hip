@@ -31,9 +31,17 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "marl_env.h"
+
+// Scratch of marl_lambda2_from_bits_static, the entry point for callers that cannot allocate: what
+// marl_lambda2_from_bits takes as its `workspace` argument lives here instead.  Every GPU the library
+// runs on holds its own copy of this array, at its own address, until the process ends; host code
+// reaches it only through the per-device address that static_scratch() looks up once
+// (hipGetSymbolAddress) -- the array's name itself is not a device address on the host side.
+static __device__ __align__(256) unsigned char scratch[MARL_STATIC_SCRATCH_BYTES];
 
 namespace {
 
@@ -2598,6 +2606,27 @@ double largest_reaching_d2(double P_w, double wavelength, double threshold_w) {
     return out;
 }
 
+// Device address of `scratch` on the current device, looked up on the first call per device.
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices] = {};
+int static_scratch(void** out) {
+    int dev = -1;
+    int rc = hip_check(hipGetDevice(&dev));
+    if (rc != MARL_OK) return rc;
+    if (dev < 0 || dev >= kMaxDevices) return MARL_EUNSUPPORTED;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* ptr = nullptr;
+        rc = hip_check(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+        if (rc != MARL_OK) return rc;
+        if (ptr == nullptr) return MARL_EHIP;
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return MARL_OK;
+}
+
 int check_sizes(const MarlEnvParams* p) {
     if (p == nullptr) return MARL_EINVAL;
     if (p->N < 1 || p->M < 1) return MARL_EINVAL;
@@ -2660,6 +2689,7 @@ const char* marl_strerror(int code) {
         case MARL_EINVAL: return "invalid argument";
         case MARL_EUNSUPPORTED: return "size not supported by the kernels (N <= 256, M <= 64)";
         case MARL_EHIP: return "HIP runtime error";
+        case MARL_ETOOBIG: return "request needs more scratch than the static buffer holds (MARL_STATIC_SCRATCH_BYTES)";
         default: return "unknown error";
     }
 }
@@ -2849,6 +2879,22 @@ int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t* bits, double* l
     }
     MARL_DISPATCH_NPAD(N, lambda2_bits_kernel, dim3(E), wave_lds_bytes(N), stream, (int)N, bits, lambda2, (int)rounds);
     return hip_check(hipGetLastError());
+}
+
+int marl_lambda2_from_bits_static(int32_t N, int32_t E, const uint32_t* bits, double* lambda2, int32_t rounds,
+                                  void* stream) {
+    if (N < 1 || E < 1 || !bits || !lambda2) return MARL_EINVAL;
+    if (N > MARL_MAX_N) return MARL_EUNSUPPORTED;
+    const size_t need = workspace_bytes(N, E);
+    if (need > (size_t)MARL_STATIC_SCRATCH_BYTES) return MARL_ETOOBIG;
+    void* ws = nullptr;
+    if (need > 0) {
+        // Nothing in the scratch has to start at zero: the first launch writes the pending list entry of
+        // every env and the rows / matrix of every env it leaves pending before the second launch reads them.
+        const int rc = static_scratch(&ws);
+        if (rc != MARL_OK) return rc;
+    }
+    return marl_lambda2_from_bits(N, E, bits, lambda2, rounds, ws, stream);
 }
 
 int marl_dbscan(const MarlEnvParams* p, int32_t E, const double* x, const double* y, int32_t* labels,
