@@ -129,3 +129,13 @@ def check(code, what=""):
         if code == MARL_EHIP:
             msg += f" (hipError_t {lib.marl_last_hip_error()})"
         raise MarlError(f"{what}: {msg}" if what else msg)
+
+
+def normalise_device(device):
+    """torch.device with an explicit index: "cuda" becomes the current device, so that comparisons
+    with tensor.device (which always carries the index) hold."""
+    import torch
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return d

@@ -165,7 +165,7 @@ class DeviceRolloutBuffer:
                  device="cuda"):
         self.buffer_size, self.E, self.M = buffer_size, num_envs, M
         self.obs_dim, self.action_dim, self.gamma, self.gae_lambda = obs_dim, action_dim, gamma, gae_lambda
-        self.device = torch.device(device)
+        self.device = _lib.normalise_device(device)
         T, E = buffer_size, num_envs
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.device)
         self.observations = z(T + 1, E, M, obs_dim)      # slot t+1 = observation after step t
@@ -308,8 +308,8 @@ class PPOAgent:
         self.c2_initial, self.max_grad_norm = c2, max_grad_norm
         self.lr_actor_initial, self.lr_critic_initial = lr_actor, lr_critic
         self.rollout_length, self.batch_size, self.n_epochs, self.E = rollout_length, batch_size, n_epochs, num_envs
-        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu") if device == "auto" \
-            else torch.device(device)
+        self.device = _lib.normalise_device(("cuda" if torch.cuda.is_available() else "cpu") if device == "auto"
+                                            else device)
         if seed is not None:
             torch.manual_seed(seed)
         self.actor = Actor(obs_dim, hidden_dim, v_max, num_bands, log_std_min, log_std_max).to(self.device)
@@ -320,7 +320,7 @@ class PPOAgent:
         # On the GPU one minibatch step (forward, backward, clipping, both Adam steps: about a hundred
         # small launches for these 36 k parameters) is captured into a HIP graph and replayed, which
         # needs capturable optimisers with their learning rates, and the entropy weight, in device memory.
-        self._graph_update = bool(graph_update) and self.device.type == "cuda" and not _dist_on()
+        self._graph_update = bool(graph_update) and self.device.type == "cuda"
         on_gpu = self.device.type == "cuda"
         mk_lr = (lambda v: torch.tensor(float(v), device=self.device)) if on_gpu else float
         self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=mk_lr(lr_actor), capturable=on_gpu)
@@ -372,7 +372,9 @@ class PPOAgent:
         self.total_timesteps += self.E
 
     # -- learning (ppo_agent.py:250-373) ----------------------------------------
-    def update(self, last_obs, last_done) -> Dict[str, float]:
+    def update(self, last_obs, last_done, permutations=None) -> Dict[str, float]:
+        """ppo_agent.py:250-373.  `permutations` (one index array per epoch) replaces the shuffles of
+        rollout_buffer.py:251-252, for tests that replay a recorded update of the reference."""
         with torch.no_grad():
             lo = torch.from_numpy(last_obs).float().to(self.device) if isinstance(last_obs, np.ndarray) else last_obs
             if lo.dim() == 2:
@@ -382,16 +384,16 @@ class PPOAgent:
                 if not isinstance(last_done, torch.Tensor) else last_done
         self.buffer.compute_returns_and_advantages(last_value, ld)
         obs, actions, logp, adv, ret, _ = self.buffer.get_samples()
-        stats = self.optimise(obs, actions, logp, adv, ret)
+        stats = self.optimise(obs, actions, logp, adv, ret, permutations=permutations)
         self.total_updates += 1
         self.buffer.reset()
         for k, v in stats.items():
             self.training_stats[k].append(v)
         return stats
 
-    def _minibatch_step(self, b_obs, b_act, b_old, b_adv, b_ret) -> torch.Tensor:
-        """One optimiser step of ppo_agent.py:296-345; returns [actor_loss, critic_loss, entropy,
-        clip_fraction, approx_kl] as a float64 device tensor."""
+    def _forward_backward(self, b_obs, b_act, b_old, b_adv, b_ret) -> torch.Tensor:
+        """Losses and gradients of one minibatch (ppo_agent.py:296-323, 328-329); returns [actor_loss,
+        critic_loss, entropy, clip_fraction, approx_kl] as a float64 device tensor."""
         log_probs, entropy = self.actor.evaluate_actions(b_obs, b_act)
         values = self.critic.forward_pooled(b_obs).squeeze(-1)
         ratio = torch.exp(log_probs - b_old)
@@ -404,33 +406,50 @@ class PPOAgent:
         self.critic_optimizer.zero_grad(set_to_none=False)
         (actor_loss + entropy_loss).backward()
         critic_loss.backward()
-        self._sync.sync()
-        nn.utils.clip_grad_norm_(self.actor.parameters(), self.max_grad_norm)
-        nn.utils.clip_grad_norm_(self.critic.parameters(), self.max_grad_norm)
-        self.actor_optimizer.step()
-        self.critic_optimizer.step()
         with torch.no_grad():
             kl = ((ratio - 1) - torch.log(ratio)).mean()
             return torch.stack([actor_loss, critic_loss, entropy.mean(),
                                 (torch.abs(ratio - 1) > self.clip_eps).float().mean(), kl]).double()
 
+    def _apply_gradients(self):
+        """Gradient-norm clip and both Adam steps (ppo_agent.py:324-325, 330-331)."""
+        nn.utils.clip_grad_norm_(self.actor.parameters(), self.max_grad_norm)
+        nn.utils.clip_grad_norm_(self.critic.parameters(), self.max_grad_norm)
+        self.actor_optimizer.step()
+        self.critic_optimizer.step()
+
+    def _minibatch_step(self, b_obs, b_act, b_old, b_adv, b_ret) -> torch.Tensor:
+        """One optimiser step of ppo_agent.py:296-345: gradients, their average over the ranks (one flat
+        all-reduce), clip, Adam."""
+        out = self._forward_backward(b_obs, b_act, b_old, b_adv, b_ret)
+        self._sync.sync()
+        self._apply_gradients()
+        return out
+
     def _graphed_step(self, batch):
-        """Replays the captured minibatch step on `batch` (tensors of exactly batch_size rows)."""
+        """Replays the captured minibatch step on `batch` (tensors of exactly batch_size rows).  Two
+        graphs -- gradients, then clip + Adam -- so that the all-reduce between them stays an ordinary
+        call on the stream: the replayed step is the same with one rank or many."""
         if self._step_graph is None:
             self._step_static = [torch.empty_like(t) for t in batch]
             for d, t in zip(self._step_static, batch):
                 d.copy_(t)
             torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._step_out = self._minibatch_step(*self._step_static)
-            self._step_graph = g
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._step_out = self._forward_backward(*self._step_static)
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._apply_gradients()
+            self._step_graph = (g1, g2)
         for d, t in zip(self._step_static, batch):
             d.copy_(t)
-        self._step_graph.replay()
+        self._step_graph[0].replay()
+        self._sync.sync()
+        self._step_graph[1].replay()
         return self._step_out
 
-    def optimise(self, obs, actions, old_log_probs, advantages, returns, generator=None) -> Dict[str, float]:
+    def optimise(self, obs, actions, old_log_probs, advantages, returns, generator=None,
+                 permutations=None) -> Dict[str, float]:
         """The epoch / minibatch loop of ppo_agent.py:286-354 on flattened device tensors.  Works on
         any device; with torch.distributed initialised, gradients are averaged in one flat
         all-reduce per step and the epoch KL is averaged so that every rank stops together."""
@@ -439,7 +458,10 @@ class PPOAgent:
         acc = torch.zeros(len(keys), dtype=torch.float64, device=obs.device)
         steps = 0
         for epoch in range(self.n_epochs):
-            perm = torch.randperm(n, device=obs.device, generator=generator)
+            if permutations is not None:
+                perm = torch.as_tensor(np.asarray(permutations[epoch]), dtype=torch.long, device=obs.device)
+            else:
+                perm = torch.randperm(n, device=obs.device, generator=generator)
             epoch_kl = torch.zeros((), dtype=torch.float64, device=obs.device)
             nb = 0
             for s in range(0, n, self.batch_size):
@@ -491,27 +513,71 @@ class PPOAgent:
                                               "rollout_length", "batch_size", "n_epochs")}
 
     def save(self, path):
-        """Same file name and keys as the reference checkpoint (ppo_agent.py:386-420)."""
+        """Same file name and keys as the reference checkpoint (ppo_agent.py:386-420); the statistics are
+        stored as plain floats so that the file loads with weights_only=True."""
         path = Path(path)
         path.mkdir(parents=True, exist_ok=True)
+        stats = {k: [float(x) for x in v] for k, v in self.training_stats.items()}
         torch.save({"actor_state_dict": self.actor.state_dict(), "critic_state_dict": self.critic.state_dict(),
                     "actor_optimizer_state_dict": self.actor_optimizer.state_dict(),
                     "critic_optimizer_state_dict": self.critic_optimizer.state_dict(),
                     "total_timesteps": self.total_timesteps, "total_updates": self.total_updates,
-                    "training_stats": self.training_stats, "config": self._config()}, path / "ppo_agent.pt")
+                    "training_stats": stats, "config": self._config()}, path / "ppo_agent.pt")
+
+    @staticmethod
+    def _read_checkpoint(path, map_location):
+        """torch.load with the weights-only unpickler.  A checkpoint written by the reference holds
+        numpy float64 scalars in `training_stats` (np.mean of the losses, ppo_agent.py:361-371): numpy's
+        scalar constructor and dtype classes are allow-listed, nothing else."""
+        allowed = [np.dtype, type(np.dtype(np.float64)), type(np.dtype(np.float32)), type(np.dtype(np.int64))]
+        try:
+            allowed.append(np._core.multiarray.scalar)
+        except AttributeError:                       # numpy < 2
+            allowed.append(np.core.multiarray.scalar)
+        with torch.serialization.safe_globals(allowed):
+            return torch.load(Path(path) / "ppo_agent.pt", map_location=map_location, weights_only=True)
+
+    def _adopt_optimizer_state(self, opt, state_dict):
+        """load_state_dict, then this agent's own group settings again: a checkpoint from the reference
+        or from a CPU run has a float learning rate, capturable=False and step counters on the host,
+        none of which a captured Adam step on the GPU accepts (and the reverse for a GPU checkpoint
+        loaded on the CPU)."""
+        opt.load_state_dict(state_dict)
+        on_gpu = self.device.type == "cuda"
+        for g in opt.param_groups:
+            lr = float(g["lr"])
+            g["lr"] = torch.tensor(lr, device=self.device) if on_gpu else lr
+            g["capturable"] = on_gpu
+        for st in opt.state.values():
+            if "step" in st and isinstance(st["step"], torch.Tensor):
+                st["step"] = st["step"].to(self.device if on_gpu else "cpu", torch.float32)
 
     def load(self, path):
-        ck = torch.load(Path(path) / "ppo_agent.pt", map_location=self.device, weights_only=True)
+        ck = self._read_checkpoint(path, self.device)
         self.actor.load_state_dict(ck["actor_state_dict"])
         self.critic.load_state_dict(ck["critic_state_dict"])
-        self.actor_optimizer.load_state_dict(ck["actor_optimizer_state_dict"])
-        self.critic_optimizer.load_state_dict(ck["critic_optimizer_state_dict"])
-        self.total_timesteps, self.total_updates = ck["total_timesteps"], ck["total_updates"]
-        self.training_stats = ck["training_stats"]
+        self._adopt_optimizer_state(self.actor_optimizer, ck["actor_optimizer_state_dict"])
+        self._adopt_optimizer_state(self.critic_optimizer, ck["critic_optimizer_state_dict"])
+        self.total_timesteps, self.total_updates = int(ck["total_timesteps"]), int(ck["total_updates"])
+        self.training_stats = {k: [float(x) for x in v] for k, v in ck["training_stats"].items()}
+        # a captured step reads the tensors it was captured with: capture again after a load
+        self._step_graph, self._step_static = None, None
+        self._eager_steps = 0
+
+    def export_actor(self, path):
+        """`actor_state_dict.pt` for the reference's deployment controller (deploy.py:139-188): the state
+        dict its MinimalActor (deploy.py:33-92) loads strictly, i.e. trunk, velocity-mean head and band
+        head; the log-std head is not part of the deployed network."""
+        path = Path(path)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        sd = {k: v.detach().cpu().clone() for k, v in self.actor.state_dict().items()
+              if not k.startswith("log_std_head.")}
+        torch.save(sd, path)
+        return sd
 
     @classmethod
     def from_checkpoint(cls, path, device="auto", num_envs=1):
-        ck = torch.load(Path(path) / "ppo_agent.pt", map_location="cpu", weights_only=True)
+        ck = cls._read_checkpoint(path, "cpu")
         agent = cls(device=device, num_envs=num_envs, **ck["config"])
         agent.load(path)
         return agent

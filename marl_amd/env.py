@@ -133,7 +133,7 @@ class BatchedJammerEnv:
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.MarlError("BatchedJammerEnv needs a HIP device; there is no CPU implementation")
-        self.device = torch.device(device)
+        self.device = _lib.normalise_device(device)
         self.E, self.N, self.M = int(num_envs), self.cfg.N, self.cfg.M
         self.seed, self.env_offset, self.auto_reset = int(seed), int(env_offset), auto_reset
         self.params = self.cfg.to_params()
@@ -285,14 +285,17 @@ class BatchedJammerEnv:
                                                    _stream()), "marl_env_reset")
         return obs, reward, self._terminated, truncated, info
 
-    def reward_per_agent(self) -> torch.Tensor:
+    def reward_per_agent(self, lambda2: Optional[torch.Tensor] = None) -> torch.Tensor:
         """RewardCalculator.compute_per_agent (reward.py:308-360) for the current state and the lambda2 of
-        the last step: [E, M] float32."""
+        the last step (or the [E] float64 tensor given): [E, M] float32."""
         v = self.views
         out = torch.empty(self.E, self.M, dtype=torch.float32, device=self.device)
+        lam = self.lambda2 if lambda2 is None else lambda2.to(self.device, torch.float64).contiguous()
+        if tuple(lam.shape) != (self.E,):
+            raise ValueError(f"lambda2 must be [{self.E}]")
         with torch.cuda.device(self.device):
             _lib.check(self.lib.marl_reward_per_agent(
-                C.byref(self.params), self.E, self.lambda2.data_ptr(), v["lambda2_initial"].data_ptr(),
+                C.byref(self.params), self.E, lam.data_ptr(), v["lambda2_initial"].data_ptr(),
                 v["enemy_band"].data_ptr(), v["jam_x"].data_ptr(), v["jam_y"].data_ptr(), v["jam_band"].data_ptr(),
                 v["last_vx"].data_ptr(), v["last_vy"].data_ptr(), v["cent_x"].data_ptr(), v["cent_y"].data_ptr(),
                 v["n_clusters"].data_ptr(), v["ncent"].data_ptr(), v["assign"].data_ptr(), out.data_ptr(),
@@ -317,6 +320,35 @@ class BatchedJammerEnv:
 class _Box:
     def __init__(self, low, high, shape, dtype):
         self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+
+class _MultiDiscrete:
+    """`spaces.MultiDiscrete([num_bands] * M)` as far as callers of the reference read it (`nvec`)."""
+
+    def __init__(self, nvec):
+        self.nvec = np.asarray(nvec, dtype=np.int64)
+        self.shape = self.nvec.shape
+
+    def sample(self, rng=np.random):
+        return np.array([rng.randint(0, n) for n in self.nvec], dtype=np.int64)
+
+
+class _DictSpace:
+    """`spaces.Dict(velocity=Box, band=MultiDiscrete)` (jammer_env.py:239-247): item access and sample()."""
+
+    def __init__(self, **spaces):
+        self.spaces = dict(spaces)
+
+    def __getitem__(self, k):
+        return self.spaces[k]
+
+    def keys(self):
+        return self.spaces.keys()
+
+    def sample(self):
+        v = self.spaces["velocity"]
+        return {"velocity": np.random.uniform(v.low, v.high, size=v.shape).astype(v.dtype),
+                "band": self.spaces["band"].sample()}
 
 
 class _SwarmView:
@@ -381,7 +413,8 @@ class JammerEnv:
         self._b = BatchedJammerEnv(1, self.cfg, device=device, auto_reset=False, track_avg_power=True)
         self.R_jam = float(self._b.params.R_jam[2])             # default band 2.4 GHz (jammer_env.py:187-189)
         self.observation_space = _Box(0.0, 1.0, (M, 5), np.float32)
-        self.action_space = {"velocity": _Box(-v_max, v_max, (M, 2), np.float32), "band": [self.num_bands] * M}
+        self.action_space = _DictSpace(velocity=_Box(-v_max, v_max, (M, 2), np.float32),
+                                       band=_MultiDiscrete([self.num_bands] * M))
         # RNG streams of the reference: EnemySwarm.__init__ seeds the global numpy
         # generator and its own RandomState (enemy_swarm.py:87-91); the env has a
         # second RandomState (jammer_env.py:250).
@@ -392,6 +425,8 @@ class JammerEnv:
         # constructor draws of EnemySwarm (positions, headings) advance its stream
         self.enemy_swarm._rng.uniform(arena_size * 0.1, arena_size - arena_size * 0.1, size=(N, 2))
         self.enemy_swarm._rng.uniform(0, 2 * np.pi, size=N)
+        if enemy_mode == "coordinated_turn":               # _init_coordinated_turn_state (enemy_swarm.py:113-114, 133-137)
+            self.enemy_swarm._rng.uniform(-self.cfg.omega_max * 0.5, self.cfg.omega_max * 0.5, size=N)
         self.clusterer = _ClustererView(self)
         self._rng = np.random.RandomState(seed)
         self.enemy_band = 2

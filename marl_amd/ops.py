@@ -157,8 +157,7 @@ def reward_per_agent(state: torch.Tensor, handle: int, lambda2: torch.Tensor) ->
     if state.data_ptr() != env._buf.data_ptr():
         raise ValueError("state must be the buffer of the registered env")
     _check_dev(lambda2)
-    env.lambda2.copy_(lambda2)
-    return env.reward_per_agent()
+    return env.reward_per_agent(lambda2)
 
 
 @reward_per_agent.register_fake

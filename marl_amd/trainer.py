@@ -11,6 +11,7 @@ from typing import Any, Dict, Optional
 
 import torch
 
+from . import _lib
 from .agents import PPOAgent, _dist_on
 from .env import BatchedJammerEnv, EnvConfig
 
@@ -21,7 +22,7 @@ class BatchedTrainer:
                  minibatches_per_epoch: int = 32, use_graph: bool = True):
         rank = torch.distributed.get_rank() if _dist_on() else 0
         self.world = torch.distributed.get_world_size() if _dist_on() else 1
-        self.device = torch.device(device)
+        self.device = _lib.normalise_device(device)
         self.E, self.T = num_envs, rollout_length
         self.total_budget = total_timesteps
         self.env = BatchedJammerEnv(num_envs, env_cfg, seed=seed, device=self.device, auto_reset=True,

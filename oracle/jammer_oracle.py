@@ -659,6 +659,47 @@ def env_reset(p: EnvParams, st: EnvState, enemy_pos, enemy_vel, enemy_band,
     return obs, info
 
 
+def env_reset_with_retries(p: EnvParams, st: EnvState, attempts, jammer_init, jammer_bands):
+    """The retry loop of JammerEnv.reset (jammer_env.py:283-316) given the draws of each attempt.
+
+    `attempts` yields (enemy_pos, enemy_vel, enemy_band[, enemy_omega]) in the order the reference
+    draws them (attempt k > 0 comes from the streams reseeded with seed + k, or from the running
+    streams when reset() was called without a seed).  Every attempt re-clusters (:298), so the
+    "previous centroids" a later drift test sees are those of the attempt before the accepted one.
+    The loop ends at the first attempt with lambda2_initial >= min_lambda2_initial, or keeps the last
+    one after max_reset_attempts (:312-316).  The jammer draws are consumed once, after the loop
+    (:321-339).  Returns (obs, info, attempts_used)."""
+    used = 0
+    for k, a in enumerate(attempts):
+        if k >= p.max_reset_attempts:
+            break
+        used = k + 1
+        st.step_count = 0
+        st.enemy_pos = np.array(a[0], dtype=np.float64)
+        st.enemy_vel = np.array(a[1], dtype=np.float64)
+        st.enemy_band = int(a[2])
+        st.enemy_omega = np.zeros(p.N) if len(a) < 4 or a[3] is None else np.array(a[3], dtype=np.float64)
+        st.R_jam = float(compute_jam_range(db_to_watts(p.P_jammer_dbm), db_to_watts(p.P_jam_thresh_dbm),
+                                           FREQUENCY_BANDS[st.enemy_band]))
+        cluster_fit(st.clusters, st.enemy_pos, p.eps, p.min_samples, p.arena_size)
+        st.lambda2_initial, _, _ = compute_lambda2(p, st, disrupted=False)
+        if st.lambda2_initial >= p.min_lambda2_initial:
+            break
+    if p.random_jammer_start:
+        st.jammer_positions = np.array(jammer_init, dtype=np.float64)
+        st.assign = np.full(p.M, ASSIGN_NONE, dtype=np.int64)
+    else:
+        st.assign = assign_proportional(p.M, st.clusters)
+        st.jammer_positions = jammer_initial_positions(p.M, st.clusters, st.assign,
+                                                       np.asarray(jammer_init), p.arena_size)
+    st.jammer_bands = np.asarray(jammer_bands).astype(np.int32)
+    st.last_velocities = np.zeros((p.M, 2))
+    obs = build_observation(p, st.jammer_positions, st.jammer_bands, st.clusters, st.enemy_band, st.R_jam)
+    info = dict(lambda2_initial=st.lambda2_initial, lambda2_current=st.lambda2_initial,
+                enemy_band=st.enemy_band, n_clusters=st.clusters.n_clusters, step=0)
+    return obs, info, used
+
+
 def env_step(p: EnvParams, st: EnvState, action, noise, want_avg_power: bool = True):
     """JammerEnv.step (jammer_env.py:356-457) with the (N,2) enemy noise draw
     passed in.  `action` is the (M,3) array form (:376-378)."""

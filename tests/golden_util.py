@@ -69,3 +69,21 @@ def lam_close(a, b, rtol=1e-5):
     """|a-b| <= rtol*max(|b|,1): the reference returns +-1e-15 noise for
     disconnected graphs, so the tolerance is relative to max(|lambda2|, 1)."""
     return abs(a - b) <= rtol * max(abs(b), 1.0)
+
+
+def retry_cases():
+    """Cases of reset_retry.npz: (params, seed, [reset dicts in call order])."""
+    z = load("reset_retry.npz")
+    out = []
+    for c in range(int(z["n_cases"])):
+        g = lambda k: z[f"c{c}_cfg_{k}"].item()
+        p = orc.EnvParams(M=2, N=5, arena_size=g("arena_size"), max_steps=int(g("max_steps")),
+                          P_jammer_dbm=g("P_jammer_dbm"), P_jam_thresh_dbm=g("P_jam_thresh_dbm"), eps=g("eps"),
+                          random_jammer_start=bool(int(z[f"c{c}_rjs"])),
+                          max_reset_attempts=int(z[f"c{c}_max_attempts"]))
+        recs = []
+        for r in range(int(z[f"c{c}_nresets"])):
+            pre = f"c{c}_r{r}_"
+            recs.append({k[len(pre):]: z[k] for k in z.files if k.startswith(pre)})
+        out.append((p, int(z[f"c{c}_seed"]), recs))
+    return out

@@ -144,3 +144,79 @@ def test_flat_grad_sync_is_noop_without_process_group():
     g = m.weight.grad.clone()
     FlatGradSync([m]).sync()
     assert torch.equal(m.weight.grad, g)
+
+
+# ---------------------------------------------------------------- the reference's own update, replayed
+def _load_ppo_golden():
+    import golden_util as gu
+    z = gu.load("ppo_update.npz")
+    T, M, B, epochs = (int(x) for x in z["hyper"])
+    return z, T, M, B, epochs
+
+
+def _state_from(z, prefix, module):
+    sd = {k: torch.from_numpy(z[f"{prefix}_{k}"].copy()) for k in module.state_dict().keys()}
+    module.load_state_dict(sd)
+
+
+def test_optimise_reproduces_reference_update():
+    """One PPOAgent.update() of the reference (agents/ppo_agent.py:250-373; T=64, M=4, 2 epochs of 4
+    minibatches) recorded by tests/golden/make_golden.py: same initial weights, same buffer, same
+    shuffles -> same weights after the 8 optimiser steps and the same five statistics."""
+    z, T, M, B, epochs = _load_ppo_golden()
+    agent = PPOAgent(device="cpu", M=M, rollout_length=T, batch_size=B, n_epochs=epochs)
+    _state_from(z, "a0", agent.actor)
+    _state_from(z, "c0", agent.critic)
+    obs = torch.from_numpy(z["buf_obs"]).reshape(-1, 5)
+    act = torch.from_numpy(z["buf_actions"]).reshape(-1, 3)
+    logp = torch.from_numpy(z["buf_log_probs"]).reshape(-1)
+    adv = torch.from_numpy(z["adv_norm"]).reshape(-1)
+    ret = torch.from_numpy(z["returns"]).reshape(-1)
+    stats = agent.optimise(obs, act, logp, adv, ret, permutations=z["perms"])
+    for k, v in agent.actor.state_dict().items():
+        assert torch.allclose(v, torch.from_numpy(z[f"a1_{k}"]), rtol=1e-5, atol=1e-7), k
+        assert not torch.equal(v, torch.from_numpy(z[f"a0_{k}"])), k
+    for k, v in agent.critic.state_dict().items():
+        assert torch.allclose(v, torch.from_numpy(z[f"c1_{k}"]), rtol=1e-5, atol=1e-7), k
+    want = dict(zip(("actor_loss", "critic_loss", "entropy", "clip_fraction", "approx_kl"), z["stats"]))
+    for k in want:
+        assert abs(stats[k] - want[k]) <= 1e-5 * max(1.0, abs(want[k])), (k, stats[k], want[k])
+    # the recorded log-probs are the ones this actor assigns to the recorded actions
+    agent2 = PPOAgent(device="cpu", M=M)
+    _state_from(z, "a0", agent2.actor)
+    with torch.no_grad():
+        lp, _ = agent2.actor.evaluate_actions(obs, act)
+    unclamped = act[:, :2].abs().max(dim=1).values < 5.0
+    assert torch.allclose(lp[unclamped], logp[unclamped], atol=1e-5)
+
+
+def test_reference_checkpoint_loads_and_deploy_export_matches_minimal_actor(tmp_path):
+    """ppo_agent.pt written by the reference's PPOAgent.save (float learning rates, capturable=False,
+    numpy scalars in training_stats) loads with the weights-only loader; the exported actor state dict
+    has exactly the keys and shapes of the reference's deployment network (deploy.py:33-92)."""
+    import golden_util as gu
+    z, T, M, B, epochs = _load_ppo_golden()
+    import os
+    agent = PPOAgent.from_checkpoint(os.path.join(gu.GOLDEN, "ref_ckpt"), device="cpu")
+    assert agent.rollout_length == T and agent.batch_size == B and agent.total_updates == 1
+    assert agent.total_timesteps == T and len(agent.training_stats["actor_loss"]) == 1
+    assert isinstance(agent.training_stats["approx_kl"][0], float)
+    for k, v in agent.actor.state_dict().items():
+        assert torch.equal(v, torch.from_numpy(z[f"a1_{k}"])), k
+    st = agent.actor_optimizer.state[next(iter(agent.actor.parameters()))]
+    assert float(st["step"]) == 2 * (T * M // B) and st["exp_avg"].abs().sum() > 0
+    # it keeps training after the load
+    obs, act, old, adv, ret = _fake_rollout(256, 2)
+    with torch.no_grad():
+        old = agent.actor.evaluate_actions(obs, act)[0]
+    assert all(np.isfinite(v) for v in agent.optimise(obs, act, old, adv, ret).values())
+    sd = agent.export_actor(tmp_path / "deployment" / "actor_state_dict.pt")
+    loaded = torch.load(tmp_path / "deployment" / "actor_state_dict.pt", weights_only=True)
+    keys = [str(k) for k in z["deploy_keys"]]
+    assert list(loaded.keys()) == keys
+    for k, shp in zip(keys, z["deploy_shapes"]):
+        assert list(loaded[k].shape) == [int(x) for x in shp[:loaded[k].dim()]], k
+    # own checkpoints round-trip through the same loader with plain-float statistics
+    agent.save(tmp_path / "own")
+    again = PPOAgent.from_checkpoint(tmp_path / "own", device="cpu")
+    assert again.training_stats == agent.training_stats

@@ -139,3 +139,146 @@ def test_tall_linear_gradients_match_nn_linear(fin, fout):
     scale = float(b.weight.grad.abs().max())
     assert float((a.weight.grad - b.weight.grad).abs().max()) <= 2e-5 * scale
     assert float((a.bias.grad - b.bias.grad).abs().max()) <= 2e-5 * float(b.bias.grad.abs().max())
+
+
+# ---------------------------------------------------------------- the reference's PPO update on the device
+def _ppo_golden():
+    import golden_util as gu
+    z = gu.load("ppo_update.npz")
+    T, M, B, epochs = (int(x) for x in z["hyper"])
+    return z, T, M, B, epochs
+
+
+def _load_state(z, prefix, module):
+    module.load_state_dict({k: torch.from_numpy(z[f"{prefix}_{k}"].copy()) for k in module.state_dict().keys()})
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_update_reproduces_reference_update_on_device(graph):
+    """PPOAgent.update of the reference (agents/ppo_agent.py:250-373) recorded with its weights before and
+    after: the device agent (E = 1) is given the same weights, the same 64 transitions through
+    DeviceRolloutBuffer.add, the same shuffles; GAE runs in marl_gae, the eight optimiser steps on the GPU
+    (eagerly, and with the two-graph replay after the first two).  Statistics to 1e-4.  Weights: Adam divides
+    the gradient by its running magnitude, so in these first steps an element whose gradient is near zero
+    moves by up to the learning rate in a direction that float32 summation order decides; the bar is
+    therefore on the update itself -- every element within 1 % of the tensor's largest change, and the
+    mean deviation below 0.1 % of it."""
+    z, T, M, B, epochs = _ppo_golden()
+    agent = PPOAgent(device="cuda", M=M, rollout_length=T, batch_size=B, n_epochs=epochs, num_envs=1,
+                     graph_update=graph)
+    _load_state(z, "a0", agent.actor)
+    _load_state(z, "c0", agent.critic)
+    for t in range(T):
+        agent.store_transition(z["buf_obs"][t][None], z["buf_actions"][t][None], z["buf_log_probs"][t][None],
+                               z["buf_rewards"][t:t + 1], z["buf_dones"][t:t + 1] > 0, z["buf_values"][t:t + 1])
+    stats = agent.update(torch.from_numpy(z["last_obs"]).cuda()[None], torch.zeros(1, dtype=torch.bool, device="cuda"),
+                         permutations=z["perms"])
+    if graph:
+        assert agent._step_graph is not None            # steps 3..8 were replays
+    for prefix, net in (("a1", agent.actor), ("c1", agent.critic)):
+        for k, v in net.state_dict().items():
+            want = torch.from_numpy(z[f"{prefix}_{k}"]).cuda()
+            moved = float((want - torch.from_numpy(z[f"{prefix[0]}0_{k}"]).cuda()).abs().max())
+            err = (v - want).abs()
+            assert float(err.max()) <= 1e-2 * moved + 1e-7, (k, float(err.max()), moved)
+            assert float(err.mean()) <= 1e-3 * moved + 1e-8, (k, float(err.mean()), moved)
+    want = dict(zip(("actor_loss", "critic_loss", "entropy", "clip_fraction", "approx_kl"), z["stats"]))
+    for k in want:
+        assert abs(stats[k] - want[k]) <= 1e-4 * max(1.0, abs(want[k])), (k, stats[k], want[k])
+
+
+def test_gpu_checkpoint_resume_and_reference_checkpoint_then_update(tmp_path):
+    """save -> from_checkpoint -> update() on the GPU (the loaded optimiser must again be capturable, with
+    device learning rates and step counters), and the same from a checkpoint the reference wrote."""
+    import os
+    import golden_util as gu
+    obs = torch.rand(2048, 5, device="cuda")
+    act = torch.cat([torch.randn(2048, 2, device="cuda"), torch.randint(0, 4, (2048, 1), device="cuda").float()], 1)
+    adv, ret = torch.randn(2048, device="cuda"), torch.randn(2048, device="cuda")
+
+    def run(agent, n):
+        with torch.no_grad():
+            old = agent.actor.evaluate_actions(obs, act)[0]
+        g = torch.Generator(device="cuda").manual_seed(n)
+        return agent.optimise(obs, act, old, adv, ret, generator=g)
+
+    a = PPOAgent(device="cuda", M=4, batch_size=256, n_epochs=1, seed=3)
+    run(a, 1)                                             # 8 steps: 2 eager, capture, 5 replays
+    a.save(tmp_path / "ck")
+    b = PPOAgent.from_checkpoint(tmp_path / "ck", device="cuda")
+    assert isinstance(b.actor_optimizer.param_groups[0]["lr"], torch.Tensor)
+    assert b.actor_optimizer.param_groups[0]["capturable"] is True
+    sa, sb = run(a, 2), run(b, 2)
+    for k in sa:
+        assert abs(sa[k] - sb[k]) <= 1e-5 * max(1.0, abs(sa[k])), k
+    for p, q in zip(a.actor.parameters(), b.actor.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7)
+    b.set_learning_rate(1e-5, 2e-5)                       # reaches the replayed step
+    assert abs(float(b.actor_optimizer.param_groups[0]["lr"]) - 1e-5) < 1e-12
+    run(b, 3)
+    # GPU checkpoint on the CPU
+    c = PPOAgent.from_checkpoint(tmp_path / "ck", device="cpu")
+    assert c.actor_optimizer.param_groups[0]["capturable"] is False
+    c.optimise(obs.cpu(), act.cpu(), torch.zeros(2048), adv.cpu(), ret.cpu())
+    # the reference's file: float lr, capturable False, host step counters, numpy scalars in the statistics
+    r = PPOAgent.from_checkpoint(os.path.join(gu.GOLDEN, "ref_ckpt"), device="cuda")
+    assert r.actor_optimizer.param_groups[0]["capturable"] is True
+    st = r.actor_optimizer.state[next(iter(r.actor.parameters()))]
+    assert st["step"].is_cuda and float(st["step"]) == 8.0
+    r.batch_size = 256
+    out = run(r, 4)
+    assert r._step_graph is not None and all(np.isfinite(v) for v in out.values())
+
+
+# ---------------------------------------------------------------- BASELINE configs[4]: rollouts at N=50, M=8
+def test_rollout_into_device_buffer_matches_oracle_n50_m8():
+    """The collection loop of the batched trainer (policy on the device -> marl_env_step writing the
+    transition into the buffer slot -> masked auto-reset) at the training configuration's swarm size,
+    checked slot by slot against the oracle fed with the policy's actions and the noise the device
+    generator draws; the episodes end inside the rollout, so the post-reset observation and the `done`
+    flag of the slot are covered too."""
+    E, N, M, T, LEN = 12, 50, 8, 26, 11
+    cfg = EnvConfig.fast_preset(N=N, M=M, max_steps=LEN)
+    p = orc.EnvParams.fast_preset(N=N, M=M)
+    p.max_steps = LEN
+    env = BatchedJammerEnv(E, cfg, seed=9, auto_reset=True)
+    agent = PPOAgent(M=M, rollout_length=T, num_envs=E, device="cuda", seed=4)
+    obs, _ = env.reset()
+    torch.cuda.synchronize()
+    v = env.views
+
+    def oracle_reset(e, st):
+        epos = np.stack([v["enemy_x"][e].cpu().numpy(), v["enemy_y"][e].cpu().numpy()], 1)
+        evel = np.stack([v["enemy_vx"][e].cpu().numpy(), v["enemy_vy"][e].cpu().numpy()], 1)
+        jpos = np.stack([v["jam_x"][e].cpu().numpy(), v["jam_y"][e].cpu().numpy()], 1)
+        return orc.env_reset(p, st, epos, evel, int(v["enemy_band"][e]), jpos, v["jam_band"][e].cpu().numpy())[0]
+
+    states = [orc.EnvState.empty(p) for _ in range(E)]
+    for e in range(E):
+        np.testing.assert_allclose(obs[e].cpu().numpy(), oracle_reset(e, states[e]), rtol=1e-5, atol=1e-6)
+    ends = 0
+    for t in range(T):
+        noise = env.fill_noise().cpu().numpy()
+        actions, rew_out, done_out, obs_out = agent.act_into_buffer(obs)
+        obs, reward, _, trunc, info = env.step(actions, out_obs=obs_out, out_reward=rew_out, out_truncated=done_out)
+        agent.commit_step()
+        torch.cuda.synchronize()
+        b = agent.buffer
+        act = b.actions[t].cpu().numpy()
+        assert act[..., :2].min() >= -5.0 and act[..., :2].max() <= 5.0
+        for e in range(E):
+            o, r, _, tr, inf = orc.env_step(p, states[e], act[e], noise[e], want_avg_power=False)
+            assert abs(float(b.rewards[t, e]) - r) <= 1e-5 * max(1.0, abs(r)), (t, e)
+            assert bool(b.dones_u8[t, e]) == tr
+            assert abs(float(info["lambda2_current"][e]) - inf["lambda2_current"]) <= 1e-5 * max(1.0, abs(inf["lambda2_current"]))
+            if tr:                                        # the slot holds the first observation of the next episode
+                ends += 1
+                assert int(v["step_count"][e]) == 0
+                o = oracle_reset(e, states[e])
+            else:
+                assert np.array_equal(v["enemy_x"][e].cpu().numpy(), states[e].enemy_pos[:, 0])
+                assert np.array_equal(v["labels"][e].cpu().numpy(), states[e].clusters.labels)
+            np.testing.assert_allclose(b.observations[t + 1, e].cpu().numpy(), o, rtol=1e-5, atol=1e-6)
+    assert ends == 2 * E and agent.buffer.full
+    stats = agent.update(obs, trunc)
+    assert all(np.isfinite(x) for x in stats.values())

@@ -249,3 +249,32 @@ def test_trajectory(name):
         assert trunc == bool(z["trunc"][t])
         if trunc:
             do_reset(resets[t + 1])
+
+
+# ---------------------------------------------------------------- reset retry loop
+def test_reset_retry_loop_matches_reference():
+    """jammer_env.py:283-316 with attempts that fail the lambda2_initial test: the oracle's loop, fed
+    the recorded draws of every attempt, ends in the reference's state (accepted attempt, cluster
+    tables, previous centroids = those of the attempt before, jammers placed from the last fit)."""
+    for p, seed, recs in gu.retry_cases():
+        st = orc.EnvState.empty(p)
+        for r in recs:
+            n_att = int(r["n_attempts"])
+            attempts = [(r["att_epos"][k], r["att_evel"][k], int(r["att_band"][k])) for k in range(n_att)]
+            # more draws offered than the reference used: the loop must stop by itself
+            attempts.append((r["att_epos"][0], r["att_evel"][0], int(r["att_band"][0])))
+            init = r["jpos"] if p.random_jammer_start else r["offsets"]
+            obs, info, used = orc.env_reset_with_retries(p, st, attempts, init, r["jb"])
+            assert used == n_att
+            assert info["lambda2_initial"] == float(r["lam0"])
+            assert (info["lambda2_initial"] >= p.min_lambda2_initial) or used == p.max_reset_attempts
+            assert np.array_equal(st.enemy_pos, r["epos"]) and st.enemy_band == int(r["band"])
+            assert np.array_equal(st.clusters.labels.astype(np.int32), r["labels"])
+            nc, pnc = int(r["ncent"]), int(r["prev_ncent"])
+            assert st.clusters.ncent == nc and st.clusters.prev_ncent == pnc
+            assert np.array_equal(st.clusters.cent_xy[:nc], r["cent_xy"][:nc])
+            assert np.array_equal(st.clusters.prev_xy[:pnc], r["prev_xy"][:pnc])
+            assert st.clusters.prev_ids() == [int(x) for x in r["prev_ids"][:pnc]]
+            assert np.array_equal(st.assign.astype(np.int32), r["assign"])
+            assert np.array_equal(st.jammer_positions, r["jpos"])
+            np.testing.assert_allclose(obs, r["obs"], rtol=1e-6, atol=1e-7)
