@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """Benchmark of the batched JammerEnv step on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu E]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4,5}] [--envs-per-gpu E]
 
-One "step" = one JammerEnv.step for every env of the batch (full step: action
-decode, enemy dynamics, DBSCAN every 10th step, FSPL adjacency, jamming mask,
-lambda2, reward, observation) plus the masked auto-reset of truncated envs.
-Workload: BASELINE.json configs[2] -- N=50 enemies, M=8 jammers, fast-preset
-physics, uniform random actions, 8,192 envs per GPU (65,536 over 8 GPUs, weak
-scaling, no collective on the data path).  Inputs (state, action pool) are
-resident in HBM before the timed region.
+--config picks one of BASELINE.json's configurations (default 3, the one the headline metric is quoted on):
 
-Prints ONE JSON line on rank 0 (metric env-steps/s whole job) with a `roofline`
-object for the step kernel and a `cpu_baseline` object (the numpy restatement of
-the reference step, timed on this box's host cores).
+  2  4,096 envs, N=10, M=4, "step + reward only": no re-clustering inside the step, no observation output
+  3  8,192 envs per GPU (65,536 over 8 GPUs), N=50, M=8, full step incl. DBSCAN every 10th step + lambda2
+  4  8,192 envs, N=200, M=16, full step (large swarm: the eigen-solve dominates)
+  5  16,384 envs, N=50, M=8, PPO training: policy inference -> step -> device rollout buffer (T=64), then the
+     PPO update; a "step" is one collection step, `value` counts the update time in (end to end), the
+     collection rate alone is reported beside it
+
+One "step" = one JammerEnv.step for every env of the batch plus the masked auto-reset of truncated envs.
+Fast-preset physics, uniform random actions from a device-resident pool (configs 2-4), weak scaling over
+GPUs with no collective on the data path (config 5: one flat gradient all-reduce per optimiser step).  Inputs
+are resident in HBM before the timed region.  The envs are stepped, untimed, to 10 steps before the end of
+their episode first, so that even a 20-step run contains an auto-reset of the whole batch.
+
+Prints ONE JSON line on rank 0 with a `roofline` object for the step (HIP events on the launch stream around
+the whole timed loop) and a `cpu_baseline` object (the numpy restatement of the reference step at the same
+N, M, timed on this box's host cores).
 """
 import argparse
 import json
@@ -24,32 +31,39 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_ENEMY, M_JAM = 50, 8
-# Algorithmic cost model of one env-step (flops, bytes):
-#   4/3 N^3 (tridiagonalise L) + 3 M N^2 (midpoint tests, symmetric half) + 3.3 N^2 (FSPL + DBSCAN/10)
-#   + 60 N (dynamics) + 10 M^2 + 3 M N (reward, observation)
-#   bytes: enemy pos+vel r/w 32N, jammer state 16M, actions 12M, obs 20M, centroid table 6N, scalars 64
-
-
-def flops_per_env_step(N, M):
-    return 4.0 / 3.0 * N ** 3 + 3.0 * M * N * N + 3.3 * N * N + 60.0 * N + 10.0 * M * M + 3.0 * M * N
-
-
-def bytes_per_env_step(N, M):
-    return 32.0 * N + 16.0 * M + 12.0 * M + 20.0 * M + 6.0 * N + 64.0
-
-
+CONFIGS = {
+    2: dict(E=4096, N=10, M=4, steps=2000, warmup=100, reward_only=True,
+            name="BASELINE configs[1]: step + reward only (no re-clustering in the step, no observation output)"),
+    3: dict(E=8192, N=50, M=8, steps=400, warmup=50, reward_only=False,
+            name="BASELINE configs[2]: full JammerEnv step incl. DBSCAN + lambda2"),
+    4: dict(E=8192, N=200, M=16, steps=20, warmup=3, reward_only=False,
+            name="BASELINE configs[3]: large swarm, full step (lambda2 eigen-solve and N^2 FSPL dominate)"),
+    5: dict(E=16384, N=50, M=8, steps=128, warmup=64, reward_only=False,
+            name="BASELINE configs[4]: PPO rollouts into the device rollout buffer + PPO update"),
+}
+ROLLOUT_T = 64            # config 5: steps per rollout
 PEAK_FP32_VALU_TFLOPS = 157.3     # 256 CU x 128 lanes x 2 flop x 2.4 GHz
 PEAK_HBM_GBPS = 8000.0
 
 
+def flops_per_env_step(N, M):
+    """Algorithmic cost of one env-step: 4/3 N^3 (tridiagonalise L) + 3 M N^2 (midpoint tests, symmetric half)
+    + 3.3 N^2 (FSPL + DBSCAN/10) + 60 N (dynamics) + 10 M^2 + 3 M N (reward, observation)."""
+    return 4.0 / 3.0 * N ** 3 + 3.0 * M * N * N + 3.3 * N * N + 60.0 * N + 10.0 * M * M + 3.0 * M * N
+
+
+def bytes_per_env_step(N, M):
+    """enemy pos+vel r/w 32N, jammer state 16M, actions 12M, obs 20M, centroid table 6N, scalars 64."""
+    return 32.0 * N + 16.0 * M + 12.0 * M + 20.0 * M + 6.0 * N + 64.0
+
+
 def cpu_worker(args):
     """Times the numpy oracle (restatement of the reference step) for `seconds` on one core."""
-    seed, seconds = args
+    seed, seconds, N, M = args
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     import numpy as np
     from oracle import jammer_oracle as orc
-    p = orc.EnvParams.fast_preset(N=N_ENEMY, M=M_JAM)
+    p = orc.EnvParams.fast_preset(N=N, M=M)
     rng = np.random.RandomState(seed)
     st = orc.EnvState.empty(p)
 
@@ -72,44 +86,94 @@ def cpu_worker(args):
         n += 1
         if trunc:
             reset()
-        if (n & 31) == 0 and time.perf_counter() - t0 >= seconds:
+        if (n & 7) == 0 and time.perf_counter() - t0 >= seconds:
             break
     return n, time.perf_counter() - t0
 
 
-def cpu_baseline(seconds=8.0):
+def cpu_baseline(N, M, seconds=8.0):
     import multiprocessing as mp
     try:
         import torch
         torch.set_num_threads(1)
     except Exception:
         pass
-    n1, t1 = cpu_worker((1234, seconds))
+    n1, t1 = cpu_worker((1234, seconds, N, M))
     cores = int(os.environ.get("MARL_BENCH_CPU_CORES", min(16, os.cpu_count() or 1)))
     ctx = mp.get_context("fork")     # called before this process touches the GPU; no exec involved
     with ctx.Pool(cores) as pool:
-        res = pool.map(cpu_worker, [(1234 + i, seconds) for i in range(cores)])
+        res = pool.map(cpu_worker, [(1234 + i, seconds, N, M) for i in range(cores)])
     tot = sum(n / t for n, t in res)
     return {"value": tot, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"numpy/scipy restatement of the reference step (oracle/jammer_oracle.py), N={N_ENEMY} M={M_JAM} "
+            "sample": f"numpy/scipy restatement of the reference step (oracle/jammer_oracle.py), N={N} M={M} "
                       f"fast-preset physics, random actions, full step incl. DBSCAN every 10th step and auto-reset; "
                       f"{cores} independent single-thread processes x {seconds:.0f} s; "
                       f"1 core alone: {n1 / t1:.1f} env-steps/s",
             "single_core_value": n1 / t1}
 
 
+def profile_summary(cfg_id):
+    """Counter-derived figures of the committed rocprofv3 runs of this same command (profiles/): HBM bytes per
+    step, VALU busy %, average duration of the eigen-solve kernel.  None where no profile was taken."""
+    path = os.path.join(ROOT, "profiles", f"summary_c{cfg_id}.json")
+    if not os.path.exists(path):
+        return {}
+    try:
+        return json.load(open(path))
+    except Exception:
+        return {}
+
+
+def lambda2_stage_time(env, reps=10):
+    """The eigen-solve stage alone, live: marl_lambda2_from_bits on the jammed graphs of the current state
+    (bits from the stage ops), HIP events around `reps` calls; microseconds per call."""
+    import ctypes as C
+    import torch
+    from marl_amd import _lib
+    lib, v, E, N, M = env.lib, env.views, env.E, env.N, env.M
+    W = (N + 31) // 32
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    adj = torch.zeros(E, N, W, dtype=torch.int32, device=env.device)
+    jam = torch.zeros_like(adj)
+    _lib.check(lib.marl_adjacency_bits(C.byref(env.params), E, v["enemy_x"].data_ptr(), v["enemy_y"].data_ptr(),
+                                       v["enemy_band"].data_ptr(), adj.data_ptr(), st))
+    _lib.check(lib.marl_jam_mask_bits(C.byref(env.params), E, v["enemy_x"].data_ptr(), v["enemy_y"].data_ptr(),
+                                      v["enemy_band"].data_ptr(), v["jam_x"].data_ptr(), v["jam_y"].data_ptr(),
+                                      v["jam_band"].data_ptr(), jam.data_ptr(), st))
+    eff = (adj & ~jam).contiguous()
+    out = torch.zeros(E, dtype=torch.float64, device=env.device)
+    nb = lib.marl_lambda2_workspace_bytes(N, E)
+    ws = torch.zeros(max(nb, 8), dtype=torch.uint8, device=env.device)
+    call = lambda: _lib.check(lib.marl_lambda2_from_bits(N, E, eff.data_ptr(), out.data_ptr(), 0,
+                                                         ws.data_ptr() if nb else None, st))
+    call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--envs-per-gpu", type=int, default=8192)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
                     help="testing only: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
+    cfgd = CONFIGS[args.config]
+    N_ENEMY, M_JAM = cfgd["N"], cfgd["M"]
+    steps = args.steps if args.steps is not None else cfgd["steps"]
+    warmup = args.warmup if args.warmup is not None else cfgd["warmup"]
+    E = args.envs_per_gpu if args.envs_per_gpu is not None else cfgd["E"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -117,7 +181,7 @@ def main():
     # CPU baseline first: its worker processes are forked before anything initialises the GPU
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_seconds)
+        cpu = cpu_baseline(N_ENEMY, M_JAM, args.cpu_seconds)
 
     import torch
     from marl_amd import BatchedJammerEnv, EnvConfig
@@ -134,85 +198,137 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    E = args.envs_per_gpu
-    cfg = EnvConfig.fast_preset(N=N_ENEMY, M=M_JAM)
-    env = BatchedJammerEnv(E, cfg, seed=1234, device=dev, auto_reset=True, env_offset=rank * E)
-    env.reset()
-    # action pool: v ~ U[-5,5]^2, band ~ U{0..3}; generated on the device before the timed region
-    pool_n = 64
-    g = torch.Generator(device=dev).manual_seed(4321 + rank)
-    pool = torch.empty(pool_n, E, M_JAM, 3, device=dev, dtype=torch.float32)
-    pool[..., :2] = (torch.rand(pool_n, E, M_JAM, 2, device=dev, generator=g) - 0.5) * 10.0
-    pool[..., 2] = torch.randint(0, 4, (pool_n, E, M_JAM), device=dev, generator=g).float()
-
-    for i in range(args.warmup):
-        env.step(pool[i % pool_n])
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # HIP events around every 4th step only: an event record is a stream marker of its own and costs about
-    # a microsecond of device time each; torch records on the current stream, the one env.step launches on
-    every = 4
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range((args.steps + every - 1) // every)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(len(ev0))]
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        # env.step() = marl_env_step (three launches: front, order, solve) + the masked reset launch on the
-        # steps where an env can have reached max_steps (BatchedJammerEnv keeps host-side bounds on the
-        # step counters; here: every 200th step, all envs at once)
-        act = pool[(args.warmup + i) % pool_n]
-        if i % every == 0:
-            ev0[i // every].record()
-        env.step(act)
-        if i % every == 0:
-            ev1[i // every].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    cfg = EnvConfig.fast_preset(N=N_ENEMY, M=M_JAM, recluster=not cfgd["reward_only"])
+    extra = {}
+    if args.config == 5:
+        from marl_amd.trainer import BatchedTrainer
+        steps = max(ROLLOUT_T, (steps + ROLLOUT_T - 1) // ROLLOUT_T * ROLLOUT_T)      # whole rollouts
+        warmup = (warmup + ROLLOUT_T - 1) // ROLLOUT_T * ROLLOUT_T
+        tr = BatchedTrainer(cfg, num_envs=E, rollout_length=ROLLOUT_T, total_timesteps=10 ** 12, seed=1234, device=dev)
+        env = tr.env
+        for _ in range(max(2, warmup // ROLLOUT_T)):       # eager rollout, graph capture, first updates
+            tr.collect_rollout()
+            tr.update()
+        warmup = max(2, warmup // ROLLOUT_T) * ROLLOUT_T
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (steps // ROLLOUT_T) + 1)]
+        barrier()
+        t0 = time.perf_counter()
+        ev[0].record()
+        for r in range(steps // ROLLOUT_T):
+            tr.collect_rollout()
+            ev[2 * r + 1].record()
+            tr.update()
+            ev[2 * r + 2].record()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        coll_ms = sum(ev[2 * r].elapsed_time(ev[2 * r + 1]) for r in range(steps // ROLLOUT_T))
+        upd_ms = sum(ev[2 * r + 1].elapsed_time(ev[2 * r + 2]) for r in range(steps // ROLLOUT_T))
+        # the env step alone on this batch, for the roofline of the step kernels inside the loop
+        pool = torch.empty(8, E, M_JAM, 3, device=dev).uniform_(-5, 5)
+        pool[..., 2] = torch.randint(0, 4, (8, E, M_JAM), device=dev).float()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        solo = BatchedJammerEnv(E, cfg, seed=99, device=dev, auto_reset=True, env_offset=rank * E)
+        solo.reset()
+        for i in range(20):
+            solo.step(pool[i % 8])
+        e0.record()
+        for i in range(50):
+            solo.step(pool[i % 8])
+        e1.record()
+        torch.cuda.synchronize()
+        kern_ms = e0.elapsed_time(e1) / 50
+        extra = {"collection_env_steps_per_s": world * E * steps / (coll_ms * 1e-3),
+                 "collection_ms_per_step": coll_ms / steps,
+                 "update_s_per_rollout": upd_ms * 1e-3 / (steps // ROLLOUT_T),
+                 "rollout_length": ROLLOUT_T, "ppo_epochs": tr.agent.n_epochs,
+                 "minibatch": tr.agent.batch_size,
+                 "timed_region": "rollouts (policy inference + step + buffer writes, replayed HIP graph) and PPO updates "
+                                 "(GAE kernel, 10 epochs x 32 minibatches unless the KL test stops earlier)"}
+        env_for_stage = solo
+    else:
+        env = BatchedJammerEnv(E, cfg, seed=1234, device=dev, auto_reset=True, env_offset=rank * E,
+                               write_obs=not cfgd["reward_only"])
+        env.reset()
+        # action pool: v ~ U[-5,5]^2, band ~ U{0..3}; generated on the device before the timed region
+        pool_n = 64 if E * M_JAM <= 8192 * 16 else 16
+        g = torch.Generator(device=dev).manual_seed(4321 + rank)
+        pool = torch.empty(pool_n, E, M_JAM, 3, device=dev, dtype=torch.float32)
+        pool[..., :2] = (torch.rand(pool_n, E, M_JAM, 2, device=dev, generator=g) - 0.5) * 10.0
+        pool[..., 2] = torch.randint(0, 4, (pool_n, E, M_JAM), device=dev, generator=g).float()
+        # untimed: up to 10 steps (half the run if shorter) before the end of the episode, warm-up included
+        to_end = min(10, max(1, steps // 2))
+        preroll = (cfg.max_steps - warmup - to_end) % cfg.max_steps
+        for i in range(preroll + warmup):
+            env.step(pool[i % pool_n])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        e0.record()            # torch records on the current stream, the one env.step launches on
+        for i in range(steps):
+            env.step(pool[(preroll + warmup + i) % pool_n])
+        e1.record()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kern_ms = e0.elapsed_time(e1) / steps
+        extra = {"auto_resets_in_timed_region": (to_end <= steps) + max(0, steps - to_end) // cfg.max_steps,
+                 "untimed_preroll_steps": preroll}
+        env_for_stage = env
     if dist is not None:
         t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / len(ev0)
     lam_mean = float(env.lambda2.mean())
-    steps_per_s = world * E * args.steps / elapsed
+    steps_per_s = world * E * steps / elapsed
 
     if rank == 0:
+        stage_us = lambda2_stage_time(env_for_stage)
         F = flops_per_env_step(N_ENEMY, M_JAM)
         B = bytes_per_env_step(N_ENEMY, M_JAM)
         achieved_tflops = F * E / (kern_ms * 1e-3) / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        prof = profile_summary(args.config)
+        sched = "one launch (solve inside the wave that stepped the env)" if (N_ENEMY <= 16 or E < 1024) else \
+            ("env_step_front_kernel + solve_order_kernel + env_step_solve_kernel" if N_ENEMY <= 64
+             else "env_step_big_kernel + env_step_team_kernel")
         out = {
-            "metric": "env-steps/sec (whole node) at N=50,M=8",
-            "value": steps_per_s, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "metric": "env-steps/sec (whole node) at N=50,M=8" if args.config in (3, 5)
+                      else f"env-steps/sec (whole node) at N={N_ENEMY},M={M_JAM}",
+            "value": steps_per_s, "unit": "env-steps/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: full JammerEnv step incl. DBSCAN + lambda2, N={N_ENEMY} "
-                                   f"enemies, M={M_JAM} jammers, fast-preset physics, random actions, "
-                                   f"{E} envs per GPU ({world * E} total), auto-reset every 200 steps",
+            "config": {"workload": f"{cfgd['name']}, N={N_ENEMY} enemies, M={M_JAM} jammers, fast-preset physics, "
+                                   f"{'policy actions' if args.config == 5 else 'random actions'}, "
+                                   f"{E} envs per GPU ({world * E} total), auto-reset every {cfg.max_steps} steps",
+                       "baseline_config_index": args.config - 1,
                        "envs_per_gpu": E, "N": N_ENEMY, "M": M_JAM, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "valu", "achieved": achieved_tflops, "peak": PEAK_FP32_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
-                         "kernel": "marl_env_step = env_step_front_kernel + solve_order_kernel + env_step_solve_kernel "
-                                   "(back-to-back launches of one call; kernel_ms is their span, HIP events around every 4th step "
-                                   "of the timed region)",
+                         "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_VALU_TFLOPS,
+                         "traffic": prof.get("hbm_bytes_per_step"),
+                         "kernel": f"marl_env_step = {sched} (+ the masked reset launch on the steps that need it); "
+                                   "kernel_ms = HIP-event span of the timed loop on the launch stream / steps"
+                                   + (" (config 5: of a 50-step loop of the env step alone on the same batch)"
+                                      if args.config == 5 else ""),
                          "kernel_ms": kern_ms,
                          "algorithmic_flops_per_env_step": F,
+                         "valu_busy_pct": prof.get("valu_busy_pct"),
                          "hbm": {"algorithmic_bytes_per_env_step": B,
                                  "achieved_GBps": B * E / (kern_ms * 1e-3) / 1e9, "peak_GBps": PEAK_HBM_GBPS,
                                  "frac": B * E / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS}},
             "lambda2_mean": lam_mean,
             "us_per_env_step_kernel": kern_ms * 1e3 / E,
+            # eigen-solve stage: live, the stage op on the jammed graphs of the final state (envs in index
+            # order, connectivity test + complement compaction + solve in one wave); from the committed kernel
+            # trace, the step's own solve launch (longest first)
+            "lambda2_solve_us_per_env": prof.get("solve_kernel_us", stage_us) / E,
+            "lambda2_stage_op_us_per_env": stage_us / E,
+            "lambda2_solve_source": "profiles/summary_c%d.json (rocprofv3 kernel trace)" % args.config
+                                    if "solve_kernel_us" in prof else "live stage op",
         }
+        out.update(extra)
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_all_cores"] = steps_per_s / cpu["value"]

@@ -51,6 +51,9 @@ extern "C" {
 #define MARL_SCHEDULE_AUTO 0            /* fused for N <= 16 or fewer than 1024 envs, split otherwise */
 #define MARL_SCHEDULE_FUSED 1
 #define MARL_SCHEDULE_SPLIT 2
+#define MARL_STAGE_NO_RECLUSTER 1        /* marl_env_step leaves the K_recompute re-clustering (jammer_env.py:394-402) out:
+                                           the cluster table of the last reset stays; with MarlStepIO.obs = NULL this is the
+                                           "step + reward only" form of the step */
 
 enum {
     MARL_OK = 0,
@@ -83,7 +86,9 @@ typedef struct MarlEnvParams {
     double comm_d2_max[MARL_NUM_BANDS];  /* largest squared distance with P_R >= P_sens, per enemy band */
     double jam_d2_max[MARL_NUM_BANDS];   /* largest squared jammer-midpoint distance with P_jam >= P_thr */
     double R_jam[MARL_NUM_BANDS];        /* compute_jam_range per enemy band */
-    float dt_f32, v_max_f32, v_max_sq_f32, pad_f32;
+    float dt_f32, v_max_f32, v_max_sq_f32;
+    /* ---- input again (kept here so that the layout of the fields above does not move) ---- */
+    int32_t stage_flags;                 /* MARL_STAGE_* bits; 0 = the full step */
 } MarlEnvParams;
 
 typedef struct MarlEnvState {
@@ -120,6 +125,7 @@ typedef struct MarlEnvState {
     int32_t *solve_hist;       /* [1344] 16 histograms of solve_np (80 words apart, envs spread by index to keep the
                                   atomics uncontended); [1280] = envs to solve in this step */
     double *solve_partial;     /* [E][4] reward terms 2..5 awaiting the lambda2 term (every N) */
+    double *episode_return;    /* [E] sum of the rewards of the running episode (training/trainer.py:229-230) */
 } MarlEnvState;
 
 /* Inputs and outputs of one step.  Optional pointers may be NULL. */
@@ -128,7 +134,7 @@ typedef struct MarlStepIO {
     const double *noise;       /* [E][N][2]  enemy velocity noise draw (enemy_swarm.py:165); coordinated turn:
                                   [e][i][0] = the turn-rate draw of drone i (enemy_swarm.py:228), [e][i][1] unused.
                                   NULL = counter-based generator keyed by (seed, env, step_count) */
-    float *obs;                /* [E][M][5]  out */
+    float *obs;                /* [E][M][5]  out; NULL = the observation is not written */
     float *reward;             /* [E]        out */
     uint8_t *truncated;        /* [E]        out: step_count >= max_steps */
     double *lambda2;           /* [E]        out, optional: lambda2_current */
@@ -136,6 +142,9 @@ typedef struct MarlStepIO {
     double *avg_power_dbm;     /* [E]        out, optional: jammer_env.py:510-560 */
     uint32_t *adj_bits;        /* [E][N][ceil(N/32)] out, optional: FSPL adjacency before jamming */
     uint32_t *jam_bits;        /* [E][N][ceil(N/32)] out, optional: disrupted-links mask */
+    double *episode_stats;     /* [4] in/out, optional: every episode that ends with this step adds (atomically)
+                                  1, its return, its lambda2 reduction in percent and its length
+                                  (training/trainer.py:248-268); the caller zeroes it when it starts a rollout */
     uint64_t seed;
     uint64_t env_offset;       /* global index of env 0 of this shard (multi-GPU: rank * E) */
 } MarlStepIO;
@@ -242,6 +251,36 @@ int marl_reward_per_agent(const MarlEnvParams *p, int32_t E, const double *lambd
                           const int32_t *jam_band, const float *vx, const float *vy, const double *cent_x,
                           const double *cent_y, const int32_t *n_clusters, const int32_t *ncent,
                           const int32_t *assign, float *rewards, void *stream);
+
+/* ---- policy inference for the rollout loop ---------------------------------- */
+
+/* Inputs and outputs of marl_policy_act.  Optional pointers may be NULL. */
+typedef struct MarlPolicyIO {
+    const float *weights;      /* packed actor + critic parameters, marl_policy_weight_count(hidden) floats (layout below) */
+    const float *obs;          /* [E][M][5]  per-agent observations */
+    const int32_t *tick;       /* [E] optional: MarlEnvState.tick, mixed into the draw counter so that a replayed launch
+                                  (HIP graph: frozen arguments) still draws fresh actions after every env step */
+    float *actions;            /* [E][M][3]  out: (vx, vy) clamped to +-v_max, band as float */
+    float *log_probs;          /* [E][M]     out: log-probability of the unclamped draw */
+    float *values;             /* [E]        out, optional: critic on the mean-pooled observation */
+    uint64_t seed;
+    uint64_t env_offset;       /* global index of env 0 of this shard */
+    uint32_t call;             /* host-side call counter, part of the draw counter */
+    int32_t deterministic;     /* != 0: velocity mean and arg-max band (evaluation) */
+} MarlPolicyIO;
+
+/* PPOAgent.get_action for E envs x M agents (agents/ppo_agent.py:193-225): Actor.sample (agents/actor.py:118-202)
+ * and Critic.forward_pooled (agents/critic.py:124-134) in one launch, float32.  hidden = 64 or 128.
+ * Packed weights (floats, torch layouts: Linear.weight is [out][in]):
+ *   actor : trunk.0.weight [H][5], trunk.0.bias [H], trunk.1.weight [H], trunk.1.bias [H] (LayerNorm),
+ *           trunk.3.weight as [H/4][H][4] with entry (t, k) = (W[4t][k], W[4t+1][k], W[4t+2][k], W[4t+3][k]), trunk.3.bias [H],
+ *           trunk.4.weight [H], trunk.4.bias [H], heads as [H][8] with row j = column j of
+ *           (mu_head, log_std_head, band_head) stacked, head biases [8]
+ *   critic: network.0.weight [H][5], network.0.bias [H], network.2.weight as [H/4][H][4] (as above),
+ *           network.2.bias [H], network.4.weight [H], network.4.bias [1] */
+size_t marl_policy_weight_count(int32_t hidden);
+int marl_policy_act(int32_t E, int32_t M, int32_t hidden, float v_max, float log_std_min, float log_std_max,
+                    const MarlPolicyIO *io, void *stream);
 
 /* The enemy-noise draw the step kernel uses when MarlStepIO.noise is NULL,
  * written out as [E][N][2] for step numbers step_count[e] + 1. */

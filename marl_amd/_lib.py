@@ -17,6 +17,7 @@ MAX_N = 256
 MAX_M = 64
 ENEMY_RANDOM_WALK, ENEMY_COORDINATED_TURN = 0, 1
 SCHEDULE_AUTO, SCHEDULE_FUSED, SCHEDULE_SPLIT = 0, 1, 2
+STAGE_NO_RECLUSTER = 1
 
 MARL_OK, MARL_EINVAL, MARL_EUNSUPPORTED, MARL_EHIP, MARL_ETOOBIG = 0, -1, -2, -3, -4
 STATIC_SCRATCH_BYTES = 32 << 20
@@ -38,7 +39,7 @@ class MarlEnvParams(C.Structure):
         ("omega_max", C.c_double),
         ("comm_d2_max", C.c_double * NUM_BANDS), ("jam_d2_max", C.c_double * NUM_BANDS),
         ("R_jam", C.c_double * NUM_BANDS),
-        ("dt_f32", C.c_float), ("v_max_f32", C.c_float), ("v_max_sq_f32", C.c_float), ("pad_f32", C.c_float),
+        ("dt_f32", C.c_float), ("v_max_f32", C.c_float), ("v_max_sq_f32", C.c_float), ("stage_flags", C.c_int32),
     ]
 
 
@@ -46,7 +47,7 @@ _STATE_ARRAYS = [
     "enemy_x", "enemy_y", "enemy_vx", "enemy_vy", "enemy_omega", "jam_x", "jam_y", "jam_band", "last_vx", "last_vy",
     "step_count", "enemy_band", "tick", "lambda2_initial", "labels", "cent_x", "cent_y", "cent_size",
     "n_clusters", "ncent", "prev_x", "prev_y", "prev_n_clusters", "prev_ncent", "assign", "workspace",
-    "solve_rows", "solve_np", "solve_slot", "solve_perm", "solve_hist", "solve_partial",
+    "solve_rows", "solve_np", "solve_slot", "solve_perm", "solve_hist", "solve_partial", "episode_return",
 ]
 
 
@@ -58,7 +59,14 @@ class MarlStepIO(C.Structure):
     _fields_ = [
         ("actions", _pf), ("noise", _pd), ("obs", _pf), ("reward", _pf), ("truncated", _pu8),
         ("lambda2", _pd), ("reward_terms", _pf), ("avg_power_dbm", _pd), ("adj_bits", _pu32),
-        ("jam_bits", _pu32), ("seed", C.c_uint64), ("env_offset", C.c_uint64),
+        ("jam_bits", _pu32), ("episode_stats", _pd), ("seed", C.c_uint64), ("env_offset", C.c_uint64),
+    ]
+
+
+class MarlPolicyIO(C.Structure):
+    _fields_ = [
+        ("weights", _pf), ("obs", _pf), ("tick", _pi), ("actions", _pf), ("log_probs", _pf), ("values", _pf),
+        ("seed", C.c_uint64), ("env_offset", C.c_uint64), ("call", C.c_uint32), ("deterministic", C.c_int32),
     ]
 
 
@@ -93,6 +101,9 @@ SYMBOLS = {
                            C.c_void_p]),
     "marl_reward_per_agent": (C.c_int, [C.POINTER(MarlEnvParams), C.c_int32, _pd, _pd, _pi, _pd, _pd, _pi, _pf, _pf,
                                         _pd, _pd, _pi, _pi, _pi, _pf, C.c_void_p]),
+    "marl_policy_weight_count": (C.c_size_t, [C.c_int32]),
+    "marl_policy_act": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                  C.POINTER(MarlPolicyIO), C.c_void_p]),
     "marl_fill_noise": (C.c_int, [C.POINTER(MarlEnvParams), C.POINTER(MarlEnvState), C.c_uint64, C.c_uint64,
                                   _pd, C.c_void_p]),
 }

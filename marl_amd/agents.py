@@ -239,6 +239,28 @@ class DeviceRolloutBuffer:
         return obs, actions, log_probs, adv, ret, val
 
 
+def pack_policy_weights(actor: "Actor", critic: "Critic") -> torch.Tensor:
+    """Actor and critic parameters as the flat float32 buffer marl_policy_act reads (layout: include/marl_env.h).
+    The hidden-layer matrices are stored in groups of four output units, [H/4][H][4], so that the kernel's
+    scalar loads are contiguous."""
+    H = actor.hidden_dim
+    if actor.num_bands != 4 or actor.obs_dim != 5 or critic.hidden_dim != H:
+        raise ValueError("marl_policy_act: obs_dim 5, 4 bands and equal hidden sizes only")
+
+    def quad(w):                       # [H, H] (out, in) -> [H/4][H][4]
+        return w.detach().reshape(H // 4, 4, H).permute(0, 2, 1).reshape(-1)
+
+    t, n = actor.trunk, critic.network
+    heads_w = torch.cat([actor.mu_head.weight, actor.log_std_head.weight, actor.band_head.weight], 0).detach()    # [8, H]
+    heads_b = torch.cat([actor.mu_head.bias, actor.log_std_head.bias, actor.band_head.bias], 0).detach()
+    parts = [t[0].weight.detach().reshape(-1), t[0].bias.detach(), t[1].weight.detach(), t[1].bias.detach(),
+             quad(t[3].weight), t[3].bias.detach(), t[4].weight.detach(), t[4].bias.detach(),
+             heads_w.t().reshape(-1), heads_b,
+             n[0].weight.detach().reshape(-1), n[0].bias.detach(), quad(n[2].weight), n[2].bias.detach(),
+             n[4].weight.detach().reshape(-1), n[4].bias.detach()]
+    return torch.cat([p.float().reshape(-1) for p in parts]).contiguous()
+
+
 def _dist_on() -> bool:
     return torch.distributed.is_available() and torch.distributed.is_initialized()
 
@@ -299,6 +321,8 @@ class PPOAgent:
     (ppo_agent.py:301), two optimisers, grad-norm clip 0.5 each, KL early stop at 0.03.
     """
 
+    GRAPH_MAX_BATCH = 256
+
     def __init__(self, obs_dim=5, hidden_dim=128, M=4, v_max=5.0, num_bands=4, log_std_min=-1.0, log_std_max=0.5,
                  gamma=0.99, gae_lambda=0.95, clip_eps=0.2, lr_actor=3e-4, lr_critic=1e-3, c1=0.5, c2=0.01,
                  max_grad_norm=0.5, rollout_length=2048, batch_size=256, n_epochs=10, device="auto", num_envs=1,
@@ -320,7 +344,11 @@ class PPOAgent:
         # On the GPU one minibatch step (forward, backward, clipping, both Adam steps: about a hundred
         # small launches for these 36 k parameters) is captured into a HIP graph and replayed, which
         # needs capturable optimisers with their learning rates, and the entropy weight, in device memory.
-        self._graph_update = bool(graph_update) and self.device.type == "cuda"
+        # Replays of the captured step were checked against eager steps: exact for minibatches of 64 and 256
+        # rows, but from a few thousand rows on the replayed backward pass of the stock torch kernels returns
+        # other gradients than the eager one (and scalar statistics that are not the batch's).  The graph is
+        # therefore only used where the step is launch-bound anyway: the reference's minibatch size.
+        self._graph_update = bool(graph_update) and self.device.type == "cuda" and batch_size <= self.GRAPH_MAX_BATCH
         on_gpu = self.device.type == "cuda"
         mk_lr = (lambda v: torch.tensor(float(v), device=self.device)) if on_gpu else float
         self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=mk_lr(lr_actor), capturable=on_gpu)
@@ -337,6 +365,11 @@ class PPOAgent:
                                                         "approx_kl")}
         self.target_kl = 0.03                                  # ppo_agent.py:284
         self._sample_gen = None
+        # Acting through libmarl_env.so (marl_policy_act: both networks, the draws and the log-probabilities in
+        # one launch) needs the weights as one packed buffer, refreshed whenever they change.
+        self.policy_kernel = self.device.type == "cuda" and hidden_dim in (64, 128) and num_bands == 4 and obs_dim == 5
+        self._packed, self._packed_stale, self._act_calls = None, True, 0
+        self.seed = 0 if seed is None else int(seed)
 
     # -- acting (ppo_agent.py:193-225) ----------------------------------------
     @torch.no_grad()
@@ -351,20 +384,61 @@ class PPOAgent:
             return actions[0].cpu().numpy(), log_probs[0].cpu().numpy(), float(values[0].item())
         return actions, log_probs, values
 
+    def packed_weights(self) -> torch.Tensor:
+        if self._packed is None:
+            self._packed = pack_policy_weights(self.actor, self.critic)
+            n = _lib.load().marl_policy_weight_count(self.hidden_dim)
+            if n != self._packed.numel():
+                raise _lib.MarlError(f"packed policy weights: {self._packed.numel()} floats, the library expects {n}")
+        elif self._packed_stale:
+            self._packed.copy_(pack_policy_weights(self.actor, self.critic))      # in place: captured launches read this buffer
+        self._packed_stale = False
+        return self._packed
+
+    @torch.no_grad()
+    def act_kernel(self, obs: torch.Tensor, actions: torch.Tensor, log_probs: torch.Tensor,
+                   values: Optional[torch.Tensor], tick: Optional[torch.Tensor] = None, deterministic: bool = False,
+                   env_offset: int = 0):
+        """get_action (ppo_agent.py:193-225) for obs [E,M,5] through marl_policy_act, results written into the
+        given float32 device tensors (actions [E,M,3], log_probs [E,M], values [E] or None)."""
+        E, M = obs.shape[0], obs.shape[1]
+        for t_, shp in ((obs, (E, M, 5)), (actions, (E, M, 3)), (log_probs, (E, M))):
+            if tuple(t_.shape) != shp or t_.dtype != torch.float32 or not t_.is_contiguous() or t_.device != self.device:
+                raise ValueError("act_kernel: contiguous float32 device tensors obs [E,M,5], actions [E,M,3], log_probs [E,M]")
+        io = _lib.MarlPolicyIO()
+        io.weights, io.obs = self.packed_weights().data_ptr(), obs.data_ptr()
+        io.tick = None if tick is None else tick.data_ptr()
+        io.actions, io.log_probs = actions.data_ptr(), log_probs.data_ptr()
+        io.values = None if values is None else values.data_ptr()
+        # draw counter: the envs' step clock when given (it advances with every step, also inside a replayed
+        # graph), else the number of calls made so far
+        io.seed, io.env_offset, io.deterministic = self.seed, int(env_offset), int(deterministic)
+        io.call = 0 if tick is not None else self._act_calls & 0xFFFFFFFF
+        self._act_calls += 1
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().marl_policy_act(E, M, self.hidden_dim, float(self.v_max), float(self.actor.log_std_min),
+                                                   float(self.actor.log_std_max), C.byref(io),
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "marl_policy_act")
+
     def store_transition(self, obs, actions, log_probs, reward, done, value):
         """ppo_agent.py:227-248 (copying form)."""
         self.buffer.add(obs, actions, log_probs, reward, done, value)
         self.total_timesteps += self.E
 
     @torch.no_grad()
-    def act_into_buffer(self, obs: Optional[torch.Tensor] = None):
+    def act_into_buffer(self, obs: Optional[torch.Tensor] = None, tick: Optional[torch.Tensor] = None,
+                        env_offset: int = 0):
         """Acts on buffer slot t's observation and writes actions / log-probs / values in place;
-        returns (actions, reward_out, done_out, next_obs_out) for BatchedJammerEnv.step."""
+        returns (actions, reward_out, done_out, next_obs_out) for BatchedJammerEnv.step.  `tick` (the env's
+        step clock, views["tick"]) keys the draws of the kernel path on top of the host-side call counter."""
         obs_in, act, logp, val, rew, done, obs_out = self.buffer.slot()
         if obs is not None and obs.data_ptr() != obs_in.data_ptr():
             obs_in.copy_(obs)
-        a, lp, v = self.get_action(obs_in)
-        act.copy_(a); logp.copy_(lp); val.copy_(v)
+        if self.policy_kernel:
+            self.act_kernel(obs_in, act, logp, val, tick=tick, env_offset=env_offset)
+        else:
+            a, lp, v = self.get_action(obs_in)
+            act.copy_(a); logp.copy_(lp); val.copy_(v)
         return act, rew, done, obs_out
 
     def commit_step(self):
@@ -434,11 +508,14 @@ class PPOAgent:
             self._step_static = [torch.empty_like(t) for t in batch]
             for d, t in zip(self._step_static, batch):
                 d.copy_(t)
+            # the statistics leave the graph through a tensor of ordinary memory; each graph keeps a pool of
+            # its own (what the second one allocates must not land on anything the first one still owns)
+            self._step_out = torch.zeros(5, dtype=torch.float64, device=self.device)
             torch.cuda.synchronize(self.device)
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
-                self._step_out = self._forward_backward(*self._step_static)
-            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._step_out.copy_(self._forward_backward(*self._step_static))
+            with torch.cuda.graph(g2):
                 self._apply_gradients()
             self._step_graph = (g1, g2)
         for d, t in zip(self._step_static, batch):
@@ -454,6 +531,7 @@ class PPOAgent:
         any device; with torch.distributed initialised, gradients are averaged in one flat
         all-reduce per step and the epoch KL is averaged so that every rank stops together."""
         n = obs.shape[0]
+        self._packed_stale = True
         keys = ("actor_loss", "critic_loss", "entropy", "clip_fraction", "approx_kl")
         acc = torch.zeros(len(keys), dtype=torch.float64, device=obs.device)
         steps = 0
@@ -560,9 +638,12 @@ class PPOAgent:
         self._adopt_optimizer_state(self.critic_optimizer, ck["critic_optimizer_state_dict"])
         self.total_timesteps, self.total_updates = int(ck["total_timesteps"]), int(ck["total_updates"])
         self.training_stats = {k: [float(x) for x in v] for k, v in ck["training_stats"].items()}
+        if "c2" in ck.get("config", {}):               # the decayed entropy weight is part of a resumed run's state
+            self.set_entropy_coef(float(ck["config"]["c2"]))
         # a captured step reads the tensors it was captured with: capture again after a load
         self._step_graph, self._step_static = None, None
         self._eager_steps = 0
+        self._packed_stale = True
 
     def export_actor(self, path):
         """`actor_state_dict.pt` for the reference's deployment controller (deploy.py:139-188): the state

@@ -35,6 +35,7 @@
 #include <type_traits>
 
 #include "marl_env.h"
+#include "marl_rng.h"
 
 // Scratch of marl_lambda2_from_bits_static, the entry point for callers that cannot allocate: what
 // marl_lambda2_from_bits takes as its `workspace` argument lives here instead.  Every GPU the library
@@ -95,29 +96,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 __device__ __forceinline__ double wave_sum(double v);      // below, next to the 64-bit DPP helper
 
-// ------------------------------------------------------------------ counter-based generator
-// Philox4x32-10 (Salmon et al., SC'11).  Counter = (env index, draw index, stream id, episode/step),
-// key = seed.  Same values whatever the launch geometry.
-__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                           uint32_t k0, uint32_t k1, uint32_t out[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        const uint32_t n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {   // (0,1), 53 bits
-    const uint64_t v = ((uint64_t)hi << 21) ^ (uint64_t)(lo >> 11);
-    return ((double)(v & ((1ull << 53) - 1)) + 0.5) * (1.0 / 9007199254740992.0);
-}
-enum { STREAM_NOISE = 1, STREAM_RESET_ENEMY = 2, STREAM_RESET_JAMMER = 3, STREAM_RESET_ENV = 4 };
+using namespace marl_rng;
 
 // Two independent N(0, sigma) draws for enemy `i` of env `genv` at step `step`.
 __device__ __forceinline__ void noise_pair(uint64_t seed, uint64_t genv, uint32_t step, uint32_t i,
@@ -1000,6 +979,28 @@ __device__ __forceinline__ void store_bits(uint32_t* dst, int e, int n, int lane
 
 __device__ __forceinline__ WaveLds& carve(unsigned char* smem) { return *reinterpret_cast<WaveLds*>(smem); }
 
+// Last act of a step for env e: the reward and lambda2 outputs, and the episode bookkeeping the rollout loop
+// of the reference keeps on the host (training/trainer.py:229-268): the running return of the episode and,
+// when the episode ends with this step, its contribution to the four sums {episodes, return, lambda2
+// reduction in percent (100 (1 - lambda2_final / lambda2_initial), 0 when lambda2_initial <= 1e-10), length}.
+__device__ __forceinline__ void finish_env(const MarlEnvParams& P, const MarlEnvState& S, const MarlStepIO& io, int e,
+                                           int step, double total, double lam, double lam0) {
+    const float r = (float)total;
+    io.reward[e] = r;
+    if (io.lambda2) io.lambda2[e] = lam;
+    double ret = S.episode_return[e] + (double)r;
+    if (step >= P.max_steps) {
+        if (io.episode_stats) {
+            atomicAdd(&io.episode_stats[0], 1.0);
+            atomicAdd(&io.episode_stats[1], ret);
+            atomicAdd(&io.episode_stats[2], lam0 > 1e-10 ? 100.0 * (1.0 - lam / lam0) : 0.0);
+            atomicAdd(&io.episode_stats[3], (double)step);
+        }
+        ret = 0.0;
+    }
+    S.episode_return[e] = ret;
+}
+
 // ------------------------------------------------------------------ step kernels (N <= 64)
 // A step is three launches.  The duration of the eigen-solve depends on the graph (nothing for a
 // complete or disconnected graph, O(n'^3) otherwise), and a fused kernel, which can only take the
@@ -1092,7 +1093,7 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
     WSYNC();
     FSTAMP(0);
     // -- clusters: recompute every K steps (jammer_env.py:394-402), else load the table
-    if (step % P.K_recompute == 0) {
+    if (step % P.K_recompute == 0 && !(P.stage_flags & MARL_STAGE_NO_RECLUSTER)) {
         const int pnum = num, pncent = ncent;
         if (lane < pncent) { L.px[lane] = ccx; L.py[lane] = ccy; }    // centroids -> _prev_centroids
         for (int s = WAVE + lane; s < pncent; s += WAVE) {
@@ -1148,7 +1149,7 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
     FSTAMP(3);
     // -- reward, observation (jammer_env.py:414-438)
     const RewardOut rw = reward_obs_wave(P, n, m, lane, L, eband, num, ncent, lam, lam0, raw_vx, raw_vy);
-    if (lane < m) {
+    if (lane < m && io.obs) {
         float* o = io.obs + ((size_t)e * m + lane) * MARL_OBS_DIM;
         o[0] = rw.o0; o[1] = rw.o1; o[2] = rw.o2; o[3] = rw.o3; o[4] = rw.o4;
     }
@@ -1166,8 +1167,7 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
         if (io.avg_power_dbm) io.avg_power_dbm[e] = avgp;
         if (FUSED == 0) S.solve_np[e] = np;
         if (final_lam) {
-            io.reward[e] = (float)rw.total;
-            if (io.lambda2) io.lambda2[e] = lam;
+            finish_env(P, S, io, e, step, rw.total, lam, lam0);
         } else {
             S.solve_slot[e] = atomicAdd(&S.solve_hist[(e & (SOLVE_HIST_SUBS - 1)) * SOLVE_HIST_STRIDE + np], 1);
             double* part = S.solve_partial + (size_t)e * 4;
@@ -1244,9 +1244,9 @@ __global__ __launch_bounds__(WAVE) void env_step_solve_kernel(MarlEnvParams P, M
     if (lane == 0) {
         const double* part = S.solve_partial + (size_t)e * 4;
         double r1;
-        const double total_r = reward_total(P, lam, S.lambda2_initial[e], part[0], part[1], (float)part[2], part[3], r1);
-        io.reward[e] = (float)total_r;
-        if (io.lambda2) io.lambda2[e] = lam;
+        const double lam0 = S.lambda2_initial[e];
+        const double total_r = reward_total(P, lam, lam0, part[0], part[1], (float)part[2], part[3], r1);
+        finish_env(P, S, io, e, S.step_count[e], total_r, lam, lam0);
 #ifndef MARL_EXP_TIMING
         if (io.reward_terms) io.reward_terms[(size_t)e * 5] = (float)r1;
 #endif
@@ -1370,6 +1370,7 @@ __global__ __launch_bounds__(WAVE) void env_reset_wave_kernel(MarlEnvParams P, M
         S.step_count[e] = 0;
         S.enemy_band[e] = eband;
         S.lambda2_initial[e] = lam0;
+        S.episode_return[e] = 0.0;
     }
 }
 
@@ -2109,7 +2110,7 @@ __global__ __launch_bounds__(WAVE) void env_step_big_kernel(MarlEnvParams P, Mar
     }
     int num = St.n_clusters[e], ncent = St.ncent[e];
     WSYNC();
-    if (step % P.K_recompute == 0) {
+    if (step % P.K_recompute == 0 && !(P.stage_flags & MARL_STAGE_NO_RECLUSTER)) {
         int pnum, pncent;
         recluster_big<S>(P, St, e, n, lane, L, num, ncent, pnum, pncent);
         if (should_reassign_wave(P, lane, L, num, ncent, pnum, pncent)) {
@@ -2138,7 +2139,7 @@ __global__ __launch_bounds__(WAVE) void env_step_big_kernel(MarlEnvParams P, Mar
     const double lam = lambda2_big<S>(adj, n, lane, L, P.lambda2_rounds, St.workspace + (size_t)e * ld * ld, &pending);
     const double lam0 = St.lambda2_initial[e];
     const RewardOut rw = reward_obs_wave(P, n, m, lane, L, eband, num, ncent, lam, lam0, raw_vx, raw_vy);
-    if (lane < m) {
+    if (lane < m && io.obs) {
         float* o = io.obs + ((size_t)e * m + lane) * MARL_OBS_DIM;
         o[0] = rw.o0; o[1] = rw.o1; o[2] = rw.o2; o[3] = rw.o3; o[4] = rw.o4;
     }
@@ -2158,8 +2159,7 @@ __global__ __launch_bounds__(WAVE) void env_step_big_kernel(MarlEnvParams P, Mar
             double* part = St.solve_partial + (size_t)e * 4;
             part[0] = rw.d2; part[1] = rw.d3; part[2] = (double)rw.r3; part[3] = rw.d5;
         } else {
-            io.reward[e] = (float)rw.total;
-            if (io.lambda2) io.lambda2[e] = lam;
+            finish_env(P, St, io, e, step, rw.total, lam, lam0);
         }
     }
 }
@@ -2260,6 +2260,7 @@ __global__ __launch_bounds__(WAVE) void env_reset_big_kernel(MarlEnvParams P, Ma
         St.step_count[e] = 0;
         St.enemy_band[e] = eband;
         St.lambda2_initial[e] = lam0;
+        St.episode_return[e] = 0.0;
     }
 }
 
@@ -2501,9 +2502,9 @@ __global__ __launch_bounds__(TEAM_THREADS) void env_step_team_kernel(MarlEnvPara
         const double lam = (double)P.N - mu;
         const double* part = St.solve_partial + (size_t)e * 4;
         double r1;
-        const double total_r = reward_total(P, lam, St.lambda2_initial[e], part[0], part[1], (float)part[2], part[3], r1);
-        io.reward[e] = (float)total_r;
-        if (io.lambda2) io.lambda2[e] = lam;
+        const double lam0 = St.lambda2_initial[e];
+        const double total_r = reward_total(P, lam, lam0, part[0], part[1], (float)part[2], part[3], r1);
+        finish_env(P, St, io, e, St.step_count[e], total_r, lam, lam0);
         if (io.reward_terms) io.reward_terms[(size_t)e * 5] = (float)r1;
     }
 }
@@ -2681,6 +2682,9 @@ size_t workspace_bytes(int N, int E) {
 }  // namespace
 
 // ====================================================================== C ABI
+// for the other translation units of the library: what marl_last_hip_error reports
+extern "C" __attribute__((visibility("hidden"))) void marl_note_hip_error(int err) { g_last_hip_error = err; }
+
 extern "C" {
 
 const char* marl_strerror(int code) {
@@ -2714,7 +2718,7 @@ int marl_params_init(MarlEnvParams* p) {
     p->dt_f32 = (float)p->dt;
     p->v_max_f32 = (float)p->v_max;
     p->v_max_sq_f32 = (float)(p->v_max * p->v_max);
-    p->pad_f32 = 0.0f;
+    if (p->stage_flags & ~MARL_STAGE_NO_RECLUSTER) return MARL_EINVAL;
     if (p->lambda2_rounds <= 0) p->lambda2_rounds = 8;
     return MARL_OK;
 }
@@ -2743,6 +2747,7 @@ size_t marl_state_bytes(const MarlEnvParams* p, int32_t E) {
         b += align256(SOLVE_HIST_WORDS * 4); // solve_hist
     }
     b += align256(e * 4 * 8);                // solve_partial
+    b += align256(e * 8);                    // episode_return
     return b;
 }
 
@@ -2780,6 +2785,7 @@ int marl_state_bind(MarlEnvState* s, const MarlEnvParams* p, int32_t E, void* ba
     s->solve_perm = split ? (int32_t*)take(e * 4) : nullptr;
     s->solve_hist = split ? (int32_t*)take(SOLVE_HIST_WORDS * 4) : nullptr;
     s->solve_partial = (double*)take(e * 4 * 8);
+    s->episode_return = (double*)take(e * 8);
     return MARL_OK;
 }
 
@@ -2787,8 +2793,8 @@ int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepI
     if (p == nullptr || s == nullptr || io == nullptr) return MARL_EINVAL;
     int rc = check_sizes(p);
     if (rc != MARL_OK) return rc;
-    if (s->E < 1 || io->actions == nullptr || io->obs == nullptr || io->reward == nullptr ||
-        io->truncated == nullptr || s->enemy_x == nullptr)
+    if (s->E < 1 || io->actions == nullptr || io->reward == nullptr ||
+        io->truncated == nullptr || s->enemy_x == nullptr || s->episode_return == nullptr)
         return MARL_EINVAL;
     if (p->N > WAVE) {
         if (s->workspace == nullptr || s->solve_partial == nullptr) return MARL_EINVAL;

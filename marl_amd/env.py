@@ -60,6 +60,7 @@ class EnvConfig:
     lambda2_rounds: int = 0
     omega_max: float = 0.5          # EnemySwarm default (enemy_swarm.py:60); JammerEnv does not expose it
     step_schedule: str = "auto"     # N <= 64: "auto", "fused" (one launch per step) or "split" (three, longest solve first)
+    recluster: bool = True          # False: step() never re-clusters (the table of the last reset stays): "step + reward only"
 
     @staticmethod
     def fast_preset(N: int = 10, M: int = 4, **kw) -> "EnvConfig":
@@ -81,6 +82,7 @@ class EnvConfig:
         p.random_jammer_start = int(bool(self.random_jammer_start))
         p.max_reset_attempts = int(self.max_reset_attempts)
         p.lambda2_rounds = int(self.lambda2_rounds)
+        p.stage_flags = 0 if self.recluster else _lib.STAGE_NO_RECLUSTER
         p.arena_size, p.dt, p.v_max, p.v_enemy = float(self.arena_size), float(self.dt), float(self.v_max), float(self.v_enemy)
         p.P_tx_w, p.P_sens_w = db_to_watts(self.P_tx_dbm), db_to_watts(self.P_sens_dbm)
         p.P_jam_w, p.P_thr_w = db_to_watts(self.P_jammer_dbm), db_to_watts(self.P_jam_thresh_dbm)
@@ -104,6 +106,7 @@ _STATE_SPEC = {   # name -> (dtype, shape as function of (E, N, M))
     "n_clusters": ("i32", "E"), "ncent": ("i32", "E"), "prev_x": ("f64", "EK"), "prev_y": ("f64", "EK"),
     "prev_n_clusters": ("i32", "E"), "prev_ncent": ("i32", "E"), "assign": ("i32", "EM"),
     "solve_np": ("i32", "E"), "solve_hist": ("i32", "H"),       # front -> solve hand-over (N <= 64 only)
+    "episode_return": ("f64", "E"),
 }
 
 
@@ -126,9 +129,11 @@ class BatchedJammerEnv:
     (`lambda2_current`, `episode_lambda2_initial`).
     """
 
+    AUTO_RESET_EPISODE = 0x5EED5EED
+
     def __init__(self, num_envs: int, config: Optional[EnvConfig] = None, seed: int = 0, device="cuda",
                  auto_reset: bool = True, env_offset: int = 0, track_avg_power: bool = False,
-                 debug_bits: bool = False, **cfg_kwargs):
+                 debug_bits: bool = False, write_obs: bool = True, **cfg_kwargs):
         self.cfg = config if config is not None else EnvConfig(**cfg_kwargs)
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -136,6 +141,7 @@ class BatchedJammerEnv:
         self.device = _lib.normalise_device(device)
         self.E, self.N, self.M = int(num_envs), self.cfg.N, self.cfg.M
         self.seed, self.env_offset, self.auto_reset = int(seed), int(env_offset), auto_reset
+        self.write_obs = bool(write_obs)      # False: step() leaves the observation out (MarlStepIO.obs = NULL)
         self.params = self.cfg.to_params()
         nbytes = self.lib.marl_state_bytes(C.byref(self.params), self.E)
         if nbytes == 0:
@@ -225,11 +231,15 @@ class BatchedJammerEnv:
     # -- step ----------------------------------------------------------------
     def step(self, actions: torch.Tensor, noise: Optional[torch.Tensor] = None, *,
              out_obs: Optional[torch.Tensor] = None, out_reward: Optional[torch.Tensor] = None,
-             out_truncated: Optional[torch.Tensor] = None):
+             out_truncated: Optional[torch.Tensor] = None, episode_stats: Optional[torch.Tensor] = None,
+             episode_info: bool = True):
         """One JammerEnv.step per env.  `actions` [E,M,3] float32 on the device.
         `noise` [E,N,2] float64 replaces the on-device enemy noise generator.
         out_* let the caller have results written straight into its own storage
-        (e.g. slot t of a rollout buffer)."""
+        (e.g. slot t of a rollout buffer).  `episode_stats` [4] float64: every episode that ends with this
+        step adds 1, its return, its lambda2 reduction (%) and its length (training/trainer.py:248-268).
+        `episode_info=False` leaves the pre-reset copies `episode_lambda2_initial` / `episode_step` out of
+        `info` (two device copies per auto-reset)."""
         if actions.dtype != torch.float32 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         if tuple(actions.shape) != (self.E, self.M, 3):
@@ -243,10 +253,15 @@ class BatchedJammerEnv:
         trunc = self._trunc_u8 if out_truncated is None else out_truncated
         io = MarlStepIO()
         io.actions, io.noise = actions.data_ptr(), _ptr(noise)
-        io.obs, io.reward, io.truncated = obs.data_ptr(), reward.data_ptr(), trunc.data_ptr()
+        io.obs = obs.data_ptr() if (self.write_obs or out_obs is not None) else None
+        io.reward, io.truncated = reward.data_ptr(), trunc.data_ptr()
         io.lambda2, io.reward_terms = self.lambda2.data_ptr(), self.reward_terms.data_ptr()
         io.avg_power_dbm = _ptr(self.avg_power)
         io.adj_bits, io.jam_bits = _ptr(self.adj_bits), _ptr(self.jam_bits)
+        if episode_stats is not None:
+            if episode_stats.dtype != torch.float64 or episode_stats.numel() < 4 or episode_stats.device != self.device:
+                raise ValueError("episode_stats must be a float64 device tensor of 4 elements")
+            io.episode_stats = episode_stats.data_ptr()
         io.seed, io.env_offset = self.seed, self.env_offset
         with torch.cuda.device(self.device):
             _lib.check(self.lib.marl_env_step(C.byref(self.params), C.byref(self.state), C.byref(io), _stream()),
@@ -268,18 +283,20 @@ class BatchedJammerEnv:
             # no env can be truncated yet: nothing to reset, the episode values are the current ones
             info["episode_lambda2_initial"] = v["lambda2_initial"]
             info["episode_step"] = v["step_count"]
-            self._episode += 1            # the draws of a later reset do not depend on the launches left out
         elif self.auto_reset:
-            info["episode_lambda2_initial"] = v["lambda2_initial"].clone()
-            info["episode_step"] = v["step_count"].clone()
+            if episode_info:
+                info["episode_lambda2_initial"] = v["lambda2_initial"].clone()
+                info["episode_step"] = v["step_count"].clone()
             if b is not None:
                 # envs at max_steps start over; if even the smallest counter is there, all of them do
                 self._count_bounds = [0, 0] if b[0] >= self.cfg.max_steps else [0, self.cfg.max_steps - 1]
             rio = MarlResetIO()
             rio.mask = trunc.data_ptr()
-            rio.obs = obs.data_ptr()
-            rio.seed, rio.episode, rio.env_offset = self.seed, self._episode, self.env_offset
-            self._episode += 1
+            rio.obs = io.obs
+            # The draws of an auto-reset are keyed by the env's step clock (`tick`, never rewound) alone: the
+            # episode word stays constant, so that the launch is the same whether it is issued eagerly, left
+            # out because nothing could be done, or replayed from a captured graph.
+            rio.seed, rio.episode, rio.env_offset = self.seed, self.AUTO_RESET_EPISODE, self.env_offset
             with torch.cuda.device(self.device):
                 _lib.check(self.lib.marl_env_reset(C.byref(self.params), C.byref(self.state), C.byref(rio),
                                                    _stream()), "marl_env_reset")
