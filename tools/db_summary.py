@@ -38,7 +38,8 @@ def stats(out, dbp):
     print(open(out).read())
 
 
-STEP_KERNELS = ("env_step_front_kernel", "solve_order_kernel", "env_step_solve_kernel", "env_step_big_kernel")
+STEP_KERNELS = ("env_step_front_kernel", "solve_order_kernel", "env_step_solve_kernel", "env_step_big_kernel",
+                "env_step_team_kernel")
 
 
 def pmc(out, dbs):
@@ -65,5 +66,32 @@ def pmc(out, dbs):
     print(json.dumps(res, indent=1))
 
 
+def summary(out, stats_csv, pmc_json=None):
+    """What bench.py reads back (profiles/summary_c<n>.json): average launch duration per kernel, the duration
+    of the eigen-solve launch, and from the counter passes HBM bytes per step (FETCH_SIZE doubled as prescribed
+    for gfx950, + WRITE_SIZE; both are reported in KiB) and VALU busy per kernel
+    (SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES x 32): quad-cycles over the busy cycles of 32 SIMDs per counter instance)."""
+    res = {"kernel_avg_us": {}}
+    for row in csv.DictReader(open(stats_csv)):
+        if row["AverageNs"]:
+            res["kernel_avg_us"][row["Name"]] = float(row["AverageNs"]) / 1e3
+    for k, v in res["kernel_avg_us"].items():
+        if k.startswith(("env_step_solve_kernel", "env_step_team_kernel")):
+            res["solve_kernel_us"] = v
+    if pmc_json:
+        p = json.load(open(pmc_json))
+        ps = p["per_step"]
+        if "FETCH_SIZE" in ps and "WRITE_SIZE" in ps:
+            res["hbm_bytes_per_step"] = (2.0 * ps["FETCH_SIZE"] + ps["WRITE_SIZE"]) * 1024.0
+        pk = p["per_kernel_launch"]
+        if "SQ_ACTIVE_INST_VALU" in pk and "SQ_BUSY_CYCLES" in pk:
+            res["valu_busy_pct"] = {k: round(100.0 * pk["SQ_ACTIVE_INST_VALU"][k] * 4 / (pk["SQ_BUSY_CYCLES"][k] * 32), 1)
+                                    for k in pk["SQ_ACTIVE_INST_VALU"] if pk["SQ_BUSY_CYCLES"].get(k)}
+        res["steps_sampled"] = p.get("steps_sampled")
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
 if __name__ == "__main__":
-    {"stats": lambda: stats(sys.argv[2], sys.argv[3]), "pmc": lambda: pmc(sys.argv[2], sys.argv[3:])}[sys.argv[1]]()
+    {"stats": lambda: stats(sys.argv[2], sys.argv[3]), "pmc": lambda: pmc(sys.argv[2], sys.argv[3:]),
+     "summary": lambda: summary(*sys.argv[2:5])}[sys.argv[1]]()
