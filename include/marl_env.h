@@ -87,6 +87,8 @@ typedef struct MarlEnvParams {
     double jam_d2_max[MARL_NUM_BANDS];   /* largest squared jammer-midpoint distance with P_jam >= P_thr */
     double R_jam[MARL_NUM_BANDS];        /* compute_jam_range per enemy band */
     float dt_f32, v_max_f32, v_max_sq_f32;
+    float jam_lo_f32[MARL_NUM_BANDS], jam_hi_f32[MARL_NUM_BANDS];   /* float32 bracket of 4 jam_d2_max for the step's
+                                            first-stage test: below lo the exact test holds, above hi it fails */
     /* ---- input again (kept here so that the layout of the fields above does not move) ---- */
     int32_t stage_flags;                 /* MARL_STAGE_* bits; 0 = the full step */
 } MarlEnvParams;

@@ -39,7 +39,8 @@ class MarlEnvParams(C.Structure):
         ("omega_max", C.c_double),
         ("comm_d2_max", C.c_double * NUM_BANDS), ("jam_d2_max", C.c_double * NUM_BANDS),
         ("R_jam", C.c_double * NUM_BANDS),
-        ("dt_f32", C.c_float), ("v_max_f32", C.c_float), ("v_max_sq_f32", C.c_float), ("stage_flags", C.c_int32),
+        ("dt_f32", C.c_float), ("v_max_f32", C.c_float), ("v_max_sq_f32", C.c_float),
+        ("jam_lo_f32", C.c_float * NUM_BANDS), ("jam_hi_f32", C.c_float * NUM_BANDS), ("stage_flags", C.c_int32),
     ]
 
 

@@ -223,6 +223,7 @@ __device__ __forceinline__ void enemy_spawn(const MarlEnvParams& P, const MarlEn
 struct WaveLds {
     double sx[WAVE], sy[WAVE];        // enemy positions
     double2 sxy[WAVE];                // the same, interleaved: one 16-byte read per enemy in the pair loop
+    float2 sxyf[WAVE];                // the same in float32: first-stage jamming tests of the step
     double jx[WAVE], jy[WAVE];        // jammer positions
     unsigned long long xfer[WAVE];    // lane-to-lane hand-over of 64-bit rows
     double cx[WAVE + 2], cy[WAVE + 2];  // centroids in dict order
@@ -307,57 +308,100 @@ __device__ __forceinline__ void pair_pass(const WaveLds& L, int n, int lane, dou
     jam |= (((uint64_t)j_hi << 32) | j_lo) & keep;
 }
 
+// First stage of the jamming test in float32 (twice the float64 rate on this GPU): per pair the squared
+// doubled distance to up to KJ jammers against two thresholds that bracket the exact one by more than the
+// float32 evaluation can be off (marl_params_init derives them from the arena size: positions inside a step
+// lie in [0, A]^2).  `sure` = within the lower threshold (the exact test holds), `maybe` = within the upper one;
+// a pair that is `maybe` for some jammer and `sure` for none is settled afterwards by the exact float64
+// expression, so float32 never decides a bit.
+template <int KJ>
+__device__ __forceinline__ void jam_pass_f32(const WaveLds& L, int n, int lane, float thr_lo, float thr_hi,
+                                             const float (&q2x)[4], const float (&q2y)[4], uint64_t& sure, uint64_t& maybe) {
+    const float2 pi = L.sxyf[lane & (WAVE - 1)];
+    uint32_t s_lo = 0, s_hi = 0, m_lo = 0, m_hi = 0;
+    auto body = [&](int j, uint32_t bit, uint32_t& sb, uint32_t& mb) {
+        const float2 pj = L.sxyf[j];
+        const float sx = pi.x + pj.x, sy = pi.y + pj.y;
+        bool hs = false, hm = false;
+        static_for<0, KJ>([&](auto k) {
+            const float DX = q2x[decltype(k)::value] - sx, DY = q2y[decltype(k)::value] - sy;
+            const float d2 = fmaf(DX, DX, DY * DY);
+            hs |= (d2 <= thr_lo);
+            hm |= (d2 <= thr_hi);
+        });
+        sb |= hs ? bit : 0u;
+        mb |= hm ? bit : 0u;
+    };
+    const int n_lo = n < 32 ? n : 32;
+    for (int j = 0; j < n_lo; ++j) body(j, 1u << j, s_lo, m_lo);
+    for (int j = 32; j < n; ++j) body(j, 1u << (j - 32), s_hi, m_hi);
+    sure |= ((uint64_t)s_hi << 32) | s_lo;
+    maybe |= ((uint64_t)m_hi << 32) | m_lo;
+}
+
 // Adjacency row (communication_graph.py:41-105) and disrupted-links row (jamming.py:151-247) of
-// enemy `lane`: the first four matching jammers share the adjacency pass, further ones (rare) take
-// extra passes of four, padded with jammers that reach nothing.
+// enemy `lane` inside a step.
 //
-// Inside a step every enemy lies in [0, A]^2 (clip of the random walk, modulo of the coordinated turn),
-// so when the communication range exceeds the arena's diagonal the adjacency is the complete graph
-// and its test is skipped (`arena` > 0 enables the shortcut; the presets with A = 200 m all take it:
-// the range at 20 dBm / -90 dBm is 1.3 km at 5.8 GHz).
-__device__ __forceinline__ void pair_rows(const WaveLds& L, int n, int m, int lane, int eband, double d2_comm,
-                                          double d2_jam, double arena, uint64_t& adj, uint64_t& jam) {
-    const bool all_linked = arena > 0.0 && d2_comm >= 2.000001 * arena * arena;
-    uint64_t mm = ballot64(lane < m && L.jb[lane & (WAVE - 1)] == eband);
-    const int cnt = __popcll(mm);
-    const double thr4 = 4.0 * d2_jam;
-    double q2x[4], q2y[4];
-    auto next_four = [&]() {
+// Every enemy lies in [0, A]^2 there (clip of the random walk, modulo of the coordinated turn), so when the
+// communication range exceeds the arena's diagonal the adjacency is the complete graph and its test is
+// skipped (the presets with A = 200 m all take that path: the range at 20 dBm / -90 dBm is 1.3 km at
+// 5.8 GHz); otherwise it is one exact float64 pass.  The jamming mask goes through the float32 first stage
+// above, four matching jammers per pass, and the exact float64 form of pair_pass for the pairs it leaves open.
+__device__ __forceinline__ void pair_rows(const MarlEnvParams& P, const WaveLds& L, int n, int m, int lane, int eband,
+                                          uint64_t& adj, uint64_t& jam) {
+    const double arena = P.arena_size, d2_comm = P.comm_d2_max[eband], d2_jam = P.jam_d2_max[eband];
+    const bool all_linked = d2_comm >= 2.000001 * arena * arena;
+    const uint64_t active = (n >= 64) ? ~0ull : ((1ull << n) - 1);
+    const uint64_t keep = (lane < n) ? (active & ~(1ull << lane)) : 0ull;
+    const double no_q[4] = {1e300, 1e300, 1e300, 1e300};
+    adj = keep;
+    jam = 0;
+    if (!all_linked) {
+        uint64_t none = 0;
+        pair_pass<0, true>(L, n, lane, d2_comm, 0.0, no_q, no_q, adj, none);
+    }
+    const uint64_t matching = ballot64(lane < m && L.jb[lane & (WAVE - 1)] == eband);
+    if (matching == 0 || d2_jam < 0.0) return;
+    const float thr_lo = P.jam_lo_f32[eband], thr_hi = P.jam_hi_f32[eband];
+    uint64_t sure = 0, maybe = 0, mm = matching;
+    while (mm) {
+        float q2x[4], q2y[4];
+        int cnt = 0;
         static_for<0, 4>([&](auto k) {
-            double x = 1e300, y = 1e300;           // squares overflow to +inf: never within range
+            float x = 1e30f, y = 1e30f;              // squares overflow to +inf: never within range
             if (mm) {
                 const int j = __ffsll((unsigned long long)mm) - 1;
                 mm &= mm - 1;
-                x = 2.0 * L.jx[j]; y = 2.0 * L.jy[j];
+                x = (float)(2.0 * L.jx[j]); y = (float)(2.0 * L.jy[j]);
+                ++cnt;
             }
             q2x[decltype(k)::value] = x; q2y[decltype(k)::value] = y;
         });
-    };
-    adj = 0; jam = 0;
-    next_four();
-    if (all_linked) {
-        const uint64_t active = (n >= 64) ? ~0ull : ((1ull << n) - 1);
-        adj = (lane < n) ? (active & ~(1ull << lane)) : 0ull;
-        switch (cnt < 4 ? cnt : 4) {
-            case 0: break;
-            case 1: pair_pass<1, false>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
-            case 2: pair_pass<2, false>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
-            case 3: pair_pass<3, false>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
-            default: pair_pass<4, false>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
-        }
-    } else {
-        switch (cnt < 4 ? cnt : 4) {
-            case 0: pair_pass<0, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
-            case 1: pair_pass<1, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
-            case 2: pair_pass<2, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
-            case 3: pair_pass<3, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
-            default: pair_pass<4, true>(L, n, lane, d2_comm, thr4, q2x, q2y, adj, jam); break;
+        switch (cnt) {
+            case 1: jam_pass_f32<1>(L, n, lane, thr_lo, thr_hi, q2x, q2y, sure, maybe); break;
+            case 2: jam_pass_f32<2>(L, n, lane, thr_lo, thr_hi, q2x, q2y, sure, maybe); break;
+            case 3: jam_pass_f32<3>(L, n, lane, thr_lo, thr_hi, q2x, q2y, sure, maybe); break;
+            default: jam_pass_f32<4>(L, n, lane, thr_lo, thr_hi, q2x, q2y, sure, maybe); break;
         }
     }
-    while (mm) {
-        next_four();
-        uint64_t dummy;
-        pair_pass<4, false>(L, n, lane, d2_comm, thr4, q2x, q2y, dummy, jam);
+    jam = sure & keep;
+    uint64_t open = maybe & ~sure & keep;
+    if (ballot64(open != 0) == 0) return;
+    // exact evaluation of the pairs left open (rare: a band of a few parts per million around the radius)
+    const double thr4 = 4.0 * d2_jam;
+    const double2 pi = L.sxy[lane & (WAVE - 1)];
+    while (open) {
+        const int j = __ffsll((unsigned long long)open) - 1;
+        open &= open - 1;
+        const double2 pj = L.sxy[j];
+        const double sx = pi.x + pj.x, sy = pi.y + pj.y;
+        bool hit = false;
+        for (uint64_t mk = matching; mk; mk &= mk - 1) {
+            const int k = __ffsll((unsigned long long)mk) - 1;
+            const double DX = 2.0 * L.jx[k] - sx, DY = 2.0 * L.jy[k] - sy;
+            hit |= (DX * DX + DY * DY <= thr4);
+        }
+        if (hit) jam |= 1ull << j;
     }
 }
 
@@ -1089,6 +1133,7 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
         S.enemy_x[oi] = ex; S.enemy_y[oi] = ey; S.enemy_vx[oi] = evx; S.enemy_vy[oi] = evy;
         L.sx[lane] = ex; L.sy[lane] = ey;
         L.sxy[lane] = make_double2(ex, ey);
+        L.sxyf[lane] = make_float2((float)ex, (float)ey);
     }
     WSYNC();
     FSTAMP(0);
@@ -1131,7 +1176,7 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
     FSTAMP(1);
     // -- lambda2 of the jammed graph (jammer_env.py:464-508)
     uint64_t adj, jam;
-    pair_rows(L, n, m, lane, eband, P.comm_d2_max[eband], P.jam_d2_max[eband], arena, adj, jam);
+    pair_rows(P, L, n, m, lane, eband, adj, jam);
     store_bits(io.adj_bits, e, n, lane, adj);
     store_bits(io.jam_bits, e, n, lane, jam);
     FSTAMP(2);
@@ -2714,6 +2759,21 @@ int marl_params_init(MarlEnvParams* p) {
         volatile double ratio = p->P_jam_w / p->P_thr_w;     // compute_jam_range (fspl.py:306-308)
         volatile double a = wl / kFourPi;
         p->R_jam[b] = a * sqrt(ratio);
+    }
+    // Float32 thresholds of the step's first-stage jamming test, around 4 d2max (the doubled-distance form).
+    // With coordinates in [0, A]: the float32 inputs are off by at most 2^-24 A each, the doubled difference
+    // DX = 2q - (xi + xj) by delta = 8 2^-24 A, so d2 = DX^2 + DY^2 by at most
+    // 2 sqrt(2 d2) delta + 2 delta^2 + 4 2^-24 d2; the band is twice that, and the thresholds are moved
+    // outwards once more when they are rounded to float.
+    for (int b = 0; b < MARL_NUM_BANDS; ++b) {
+        const double t4 = 4.0 * p->jam_d2_max[b];
+        if (!(p->jam_d2_max[b] >= 0.0)) { p->jam_lo_f32[b] = -1.0f; p->jam_hi_f32[b] = -1.0f; continue; }
+        const double u = 5.9604644775390625e-08;         // 2^-24
+        const double delta = 8.0 * u * p->arena_size;
+        const double g = 2.0 * (2.0 * sqrt(2.0 * t4) * delta + 2.0 * delta * delta + 4.0 * u * t4);
+        const double lo = t4 - g, hi = t4 + g;
+        p->jam_lo_f32[b] = lo > 0.0 ? nextafterf((float)lo, -INFINITY) : -1.0f;
+        p->jam_hi_f32[b] = hi < 3.0e38 ? nextafterf((float)hi, INFINITY) : 3.4e38f;
     }
     p->dt_f32 = (float)p->dt;
     p->v_max_f32 = (float)p->v_max;

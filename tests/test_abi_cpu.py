@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_header_layout():
     # 10 int32 + 20 double + 12 double + 4 float
-    assert C.sizeof(_lib.MarlEnvParams) == 10 * 4 + 32 * 8 + 4 * 4
+    assert C.sizeof(_lib.MarlEnvParams) == 10 * 4 + 32 * 8 + 12 * 4
     assert C.sizeof(_lib.MarlEnvState) == 8 + 33 * 8
     assert C.sizeof(_lib.MarlStepIO) == 13 * 8
     assert C.sizeof(_lib.MarlPolicyIO) == 9 * 8

@@ -195,3 +195,51 @@ def test_two_shards_equal_one_batch_across_auto_resets(N, M, E):
     def digest(env):
         return sum(int(env.views[n].view(torch.uint8).to(torch.int64).sum()) for n in ("enemy_x", "jam_x", "labels"))
     assert digest(whole) == digest(halves[0]) + digest(halves[1])
+
+
+# ---------------------------------------------------------------- float32 first stage of the step's jamming test
+@pytest.mark.parametrize("arena,band", [(200.0, 0), (200.0, 3), (6000.0, 2)])
+def test_step_jamming_mask_is_exact_around_the_float32_guard_band(arena, band):
+    """The step evaluates the jamming test in float32 first and settles the pairs inside a guard band around
+    the radius with the exact float64 expression.  Link midpoints are planted at R (1 + eps) from a jammer for
+    eps from one ulp to 1e-4 on both sides (inside the band, at its edges and outside), with the enemies held
+    still (v_enemy = 0) so that the planted geometry is what the step sees: bits equal the reference expression."""
+    rng = np.random.RandomState(5)
+    eps_list = [0.0, 1.2e-16, -1.2e-16, 1e-12, -1e-12, 1e-9, -1e-9, 1e-7, -1e-7, 5e-7, -5e-7, 1e-6, -1e-6, 2e-6, -2e-6,
+                4e-6, -4e-6, 1e-5, -1e-5, 1e-4, -1e-4]
+    N, M, E = 2 * len(eps_list), 2, 8
+    p = orc.EnvParams(M=M, N=N, arena_size=arena, P_jammer_dbm=20.0 if arena < 1000 else 30.0,
+                      P_jam_thresh_dbm=-40.0 if arena < 1000 else -45.0, v_enemy=0.0, random_jammer_start=True)
+    R = orc.compute_jam_range(orc.db_to_watts(p.P_jammer_dbm), orc.db_to_watts(p.P_jam_thresh_dbm),
+                              orc.FREQUENCY_BANDS[band])
+    env = BatchedJammerEnv(E, cfg_from(p), auto_reset=False, debug_bits=True)
+    epos = np.zeros((E, N, 2))
+    jpos = np.zeros((E, M, 2))
+    for e in range(E):
+        q = rng.uniform(0.3 * arena, 0.7 * arena, size=2)
+        jpos[e, 0] = q
+        jpos[e, 1] = rng.uniform(0.1 * arena, 0.9 * arena, size=2)
+        for t, eps in enumerate(eps_list):
+            ang, half = rng.uniform(0, 2 * np.pi), rng.uniform(0.5, 0.2 * R + 0.5)
+            mid = q + R * (1.0 + eps) * np.array([np.cos(ang), np.sin(ang)])
+            d = half * np.array([-np.sin(ang), np.cos(ang)])
+            epos[e, 2 * t], epos[e, 2 * t + 1] = mid + d, mid - d
+        epos[e] = np.clip(epos[e], 0.0, arena)
+    jb = np.tile(np.array([band, (band + 1) % 4], np.int32), (E, 1))
+    env.reset(enemy_pos=epos, enemy_vel=np.tile(np.array([1.0, 0.0]), (E, N, 1)),
+              enemy_band=np.full(E, band, np.int32), jam_init=jpos, jam_band=jb)
+    act = np.zeros((E, M, 3), np.float32)
+    act[:, :, 2] = jb
+    for step in range(2):
+        env.step(torch.from_numpy(act).cuda(), torch.zeros(E, N, 2, dtype=torch.float64, device="cuda"))
+        torch.cuda.synchronize()
+        near = 0
+        for e in range(E):
+            assert np.array_equal(env.views["enemy_x"][e].cpu().numpy(), epos[e, :, 0])       # held still
+            want = orc.disrupted_links(jpos[e], jb[e], epos[e], band, orc.db_to_watts(p.P_jammer_dbm),
+                                       orc.db_to_watts(p.P_jam_thresh_dbm))
+            got = env.jam_bits[e].cpu().numpy().view(np.uint32)
+            assert np.array_equal(got, orc.pack_rows(want)), (arena, band, e)
+            dmid = orc.midpoint_distances(jpos[e, :1], epos[e])[0]
+            near += int(np.sum(np.abs(dmid / R - 1.0) < 3e-6)) // 2
+        assert near >= E * 12                                   # the planted pairs did land inside the band
