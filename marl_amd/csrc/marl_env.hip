@@ -221,8 +221,7 @@ __device__ __forceinline__ void enemy_spawn(const MarlEnvParams& P, const MarlEn
 
 // ------------------------------------------------------------------ LDS layout of one env
 struct WaveLds {
-    double sx[WAVE], sy[WAVE];        // enemy positions
-    double2 sxy[WAVE];                // the same, interleaved: one 16-byte read per enemy in the pair loop
+    double2 sxy[WAVE];                // enemy positions (x, y): one 16-byte read per enemy in the pair loops
     float2 sxyf[WAVE];                // the same in float32: first-stage jamming tests of the step
     double jx[WAVE], jy[WAVE];        // jammer positions
     unsigned long long xfer[WAVE];    // lane-to-lane hand-over of 64-bit rows
@@ -244,9 +243,9 @@ inline size_t wave_lds_bytes(int) { return sizeof(WaveLds); }
 // (xi-xj)^2 + (yi-yj)^2 <= d2max, diagonal clear.
 __device__ __forceinline__ uint64_t adjacency_row(const WaveLds& L, int n, int lane, double d2max) {
     uint64_t row = 0;
-    const double xi = L.sx[lane & (WAVE - 1)], yi = L.sy[lane & (WAVE - 1)];
+    const double xi = L.sxy[lane & (WAVE - 1)].x, yi = L.sxy[lane & (WAVE - 1)].y;
     for (int j = 0; j < n; ++j) {
-        const double dx = xi - L.sx[j], dy = yi - L.sy[j];
+        const double dx = xi - L.sxy[j].x, dy = yi - L.sxy[j].y;
         const double d2 = dx * dx + dy * dy;
         row |= (uint64_t)(d2 <= d2max) << j;
     }
@@ -258,12 +257,12 @@ __device__ __forceinline__ uint64_t adjacency_row(const WaveLds& L, int n, int l
 // jammer k on the enemy band has |q_k - (p_i + p_j)/2|^2 <= d2max; diagonal clear.
 __device__ __forceinline__ uint64_t jam_row(const WaveLds& L, int n, int m, int lane, int eband, double d2max) {
     uint64_t row = 0;
-    const double xi = L.sx[lane & (WAVE - 1)], yi = L.sy[lane & (WAVE - 1)];
+    const double xi = L.sxy[lane & (WAVE - 1)].x, yi = L.sxy[lane & (WAVE - 1)].y;
     for (int k = 0; k < m; ++k) {
         if (L.jb[k] != eband) continue;          // wave-uniform
         const double qx = L.jx[k], qy = L.jy[k];
         for (int j = 0; j < n; ++j) {
-            const double mx = (xi + L.sx[j]) / 2, my = (yi + L.sy[j]) / 2;
+            const double mx = (xi + L.sxy[j].x) / 2, my = (yi + L.sxy[j].y) / 2;
             const double dx = qx - mx, dy = qy - my;
             const double d2 = dx * dx + dy * dy;
             row |= (uint64_t)(d2 <= d2max) << j;
@@ -777,9 +776,9 @@ __device__ __forceinline__ int dbscan_wave(const MarlEnvParams& P, int n, int la
     const double eps2 = P.eps * P.eps;
     uint64_t nb = 0;
     {
-        const double xi = L.sx[lane & (WAVE - 1)], yi = L.sy[lane & (WAVE - 1)];
+        const double xi = L.sxy[lane & (WAVE - 1)].x, yi = L.sxy[lane & (WAVE - 1)].y;
         for (int j = 0; j < n; ++j) {
-            const double dx = xi - L.sx[j], dy = yi - L.sy[j];
+            const double dx = xi - L.sxy[j].x, dy = yi - L.sxy[j].y;
             const double d2 = dx * dx + dy * dy;
             nb |= (uint64_t)(d2 <= eps2) << j;
         }
@@ -813,7 +812,7 @@ __device__ __forceinline__ int dbscan_wave(const MarlEnvParams& P, int n, int la
         double ax = 0.0, ay = 0.0;
         int cnt = 0;
         for (int i = 0; i < n; ++i) {          // np.mean(axis=0): sequential sum in index order
-            if (L.lab[i] == id) { ax = ax + L.sx[i]; ay = ay + L.sy[i]; ++cnt; }
+            if (L.lab[i] == id) { ax = ax + L.sxy[i].x; ay = ay + L.sxy[i].y; ++cnt; }
         }
         L.cx[c] = ax / (double)cnt;
         L.cy[c] = ay / (double)cnt;
@@ -989,12 +988,12 @@ __device__ __forceinline__ double avg_power_wave(const MarlEnvParams& P, int n, 
     for (int k = 0; k < m; ++k) nm += (L.jb[k] == eband);
     if (nm == 0) return -80.0;
     const double wl = kSpeedOfLight / band_hz(eband);
-    const double xi = L.sx[lane & (WAVE - 1)], yi = L.sy[lane & (WAVE - 1)];
+    const double xi = L.sxy[lane & (WAVE - 1)].x, yi = L.sxy[lane & (WAVE - 1)].y;
     double psum = 0.0;
     int pcnt = 0;
     for (int j = 0; j < n; ++j) {
         double dmin = INFINITY;
-        const double mx = (xi + L.sx[j]) / 2, my = (yi + L.sy[j]) / 2;
+        const double mx = (xi + L.sxy[j].x) / 2, my = (yi + L.sxy[j].y) / 2;
         for (int k = 0; k < m; ++k) {
             if (L.jb[k] != eband) continue;
             const double dx = L.jx[k] - mx, dy = L.jy[k] - my;
@@ -1060,7 +1059,7 @@ enum { SOLVE_HIST_SUBS = 16, SOLVE_HIST_STRIDE = 80, SOLVE_HIST_TOTAL = SOLVE_HI
 // FUSED = 0: as described.  FUSED = NPAD > 0: the solve follows in the same wave (one launch per step): taken for
 // small batches and small swarms, where the extra launches cost more than the scheduling gains.
 template <int FUSED>
-__global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 ? 1 : 6, FUSED > 0 ? 4 : 8))) void env_step_front_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds& L = carve(smem);
     const int e = blockIdx.x, lane = threadIdx.x;
@@ -1131,7 +1130,6 @@ __global__ __launch_bounds__(WAVE) void env_step_front_kernel(MarlEnvParams P, M
         enemy_advance(P, ex, ey, evx, evy, ew, nx, ny);
         if (ct) S.enemy_omega[oi] = ew;
         S.enemy_x[oi] = ex; S.enemy_y[oi] = ey; S.enemy_vx[oi] = evx; S.enemy_vy[oi] = evy;
-        L.sx[lane] = ex; L.sy[lane] = ey;
         L.sxy[lane] = make_double2(ex, ey);
         L.sxyf[lane] = make_float2((float)ex, (float)ey);
     }
@@ -1323,7 +1321,7 @@ __global__ __launch_bounds__(WAVE) void env_reset_wave_kernel(MarlEnvParams P, M
         if (lane < n) {
             double x, y;
             enemy_spawn(P, S, io, e, lane, attempt, x, y);
-            L.sx[lane] = x; L.sy[lane] = y;
+            L.sxy[lane].x = x; L.sxy[lane].y = y;
         }
         if (io.enemy_band) {
             eband = io.enemy_band[e];
@@ -1425,7 +1423,7 @@ __global__ __launch_bounds__(WAVE) void adjacency_bits_kernel(MarlEnvParams P, c
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds& L = carve(smem);
     const int e = blockIdx.x, lane = threadIdx.x, n = P.N;
-    if (lane < n) { L.sx[lane] = x[(size_t)e * n + lane]; L.sy[lane] = y[(size_t)e * n + lane]; }
+    if (lane < n) { L.sxy[lane].x = x[(size_t)e * n + lane]; L.sxy[lane].y = y[(size_t)e * n + lane]; }
     WSYNC();
     int b = band[e]; b = b < 0 ? 0 : (b > 3 ? 3 : b);
     store_bits(bits, e, n, lane, adjacency_row(L, n, lane, P.comm_d2_max[b]));
@@ -1437,7 +1435,7 @@ __global__ __launch_bounds__(WAVE) void jam_bits_kernel(MarlEnvParams P, const d
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds& L = carve(smem);
     const int e = blockIdx.x, lane = threadIdx.x, n = P.N, m = P.M;
-    if (lane < n) { L.sx[lane] = x[(size_t)e * n + lane]; L.sy[lane] = y[(size_t)e * n + lane]; }
+    if (lane < n) { L.sxy[lane].x = x[(size_t)e * n + lane]; L.sxy[lane].y = y[(size_t)e * n + lane]; }
     if (lane < m) {
         L.jx[lane] = jx[(size_t)e * m + lane]; L.jy[lane] = jy[(size_t)e * m + lane];
         L.jb[lane] = jb[(size_t)e * m + lane];
@@ -1471,7 +1469,7 @@ __global__ __launch_bounds__(WAVE) void dbscan_kernel(MarlEnvParams P, const dou
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds& L = carve(smem);
     const int e = blockIdx.x, lane = threadIdx.x, n = P.N, KS = n + 1;
-    if (lane < n) { L.sx[lane] = x[(size_t)e * n + lane]; L.sy[lane] = y[(size_t)e * n + lane]; }
+    if (lane < n) { L.sxy[lane].x = x[(size_t)e * n + lane]; L.sxy[lane].y = y[(size_t)e * n + lane]; }
     WSYNC();
     int num, ncent;
     const int label = dbscan_wave(P, n, lane, L, num, ncent);
