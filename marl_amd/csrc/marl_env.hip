@@ -707,6 +707,164 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
     return sturm_largest_wave(L, np, lane, lo, hi, rounds);
 }
 
+// ---- two eigenproblems per wave (n' <= 32 each) ----------------------------------------------------------
+// Half of the step's eigenproblems have at most 32 vertices, and more than half of a Householder step's
+// instructions do not depend on the matrix size.  Two such problems share a wave: problem A in lanes 0..31,
+// problem B in lanes 32..63, both reduced in lockstep over max(n'_A, n'_B) steps (the smaller matrix is padded
+// with zero rows: its first steps find a zero column and do nothing).  The row broadcasts are local to rows of
+// 16 lanes already; sums and pivot values become per-half quantities.
+__device__ __forceinline__ double lane_xor16(double v) {           // the value of lane ^ 16 (ds_swizzle, bit mode)
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double half_sum(double v) {              // sum over the 32 lanes of the lane's half, in every lane
+    v += dpp_mov<0x128>(v);
+    v += dpp_mov<0x124>(v);
+    v += dpp_mov<0x122>(v);
+    v += dpp_mov<0x121>(v);
+    return v + lane_xor16(v);
+}
+__device__ __forceinline__ double half_lane(double v, int src, bool upper) {   // v of lane src (A) / 32 + src (B); src uniform
+    const double a = readlane_d(v, src), b = readlane_d(v, 32 + src);
+    return upper ? b : a;
+}
+
+// mu_max of both problems; `crow` = the lane's 32-bit complement row, np = max(n'_A, n'_B) <= 32, np_own = the
+// size of the lane's own problem (0: no problem in this half).  The result is valid in every lane of a half.
+template <class LDS>
+__device__ __forceinline__ double mu_max_pair_wave(uint32_t crow, int np, int np_own, int lane, LDS& L, int rounds) {
+    constexpr int NPAD = 32, KB = 2;
+    const bool upper = lane >= 32;
+    const int hl = lane & 31;
+    const int cdeg = __popc(crow);
+    int dmax = cdeg;
+    dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, 0x128, 0xF, 0xF, false));
+    dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, 0x124, 0xF, 0xF, false));
+    dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, 0x122, 0xF, 0xF, false));
+    dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, 0x121, 0xF, 0xF, false));
+    dmax = max(dmax, __builtin_amdgcn_ds_swizzle(dmax, 0x401F));
+    double a[NPAD];
+    {
+        const double dg = (double)cdeg;
+        const int dg_hi = __double2hiint(dg), dg_lo = __double2loint(dg);
+        static_for<0, NPAD>([&](auto k) {
+            constexpr int c = decltype(k)::value;
+            int hi = __builtin_amdgcn_sbfe((int)crow, c, 1) & (int)0xBFF00000, lo;
+            const uint64_t diag = (1ull << c) | (1ull << (c + 32));
+            asm("v_cndmask_b32_e64 %0, %0, %2, %4\n\tv_cndmask_b32_e64 %1, 0, %3, %4"
+                : "+v"(hi), "=v"(lo) : "v"(dg_hi), "v"(dg_lo), "s"(diag));
+            a[c] = __hiloint2double(hi, lo);
+        });
+    }
+    double col = (hl == np - 1) ? (double)cdeg : -(double)((crow >> (np - 1)) & 1u);
+    for (int i = np - 1; i >= 2; --i) {
+        const int l = i - 1;
+        const double aii = col;
+        double uj = (hl <= l) ? col : 0.0;
+        const double h = half_sum(uj * uj);
+        if (hl == i) L.de[lane] = make_double2(aii, h);
+        const double f = half_lane(uj, l, upper);
+        const double sq = (h > 0.0) ? sqrt_45(h) : 0.0;
+        const double g = (f >= 0.0) ? -sq : sq;
+        const double h2 = h - f * g;
+        if (hl == l) uj = f - g;
+        double p0 = 0.0, p1 = 0.0;
+        double U[KB], Q[KB];
+        {
+            const int ulo = __double2loint(uj), uhi = __double2hiint(uj);
+            static_for<0, KB>([&](auto kk) {
+                const int addr = ((lane & 32) + decltype(kk)::value * 16 + (lane & 15)) << 2;
+                U[decltype(kk)::value] = __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, uhi), __builtin_amdgcn_ds_bpermute(addr, ulo));
+            });
+        }
+        ColBlocks<NPAD, 0>::matvec(a, U, l, p0, p1);
+        const double hinv = (h > 0.0) ? rcp_45(h2) : 0.0;
+        const double pj = (hl <= l) ? (p0 + p1) * hinv : 0.0;
+        const double K = half_sum(uj * pj) * (0.5 * hinv);
+        const double qj = fma(-K, uj, pj);
+        {
+            const int qlo = __double2loint(qj), qhi = __double2hiint(qj);
+            static_for<0, KB>([&](auto kk) {
+                const int addr = ((lane & 32) + decltype(kk)::value * 16 + (lane & 15)) << 2;
+                Q[decltype(kk)::value] = __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, qhi), __builtin_amdgcn_ds_bpermute(addr, qlo));
+            });
+            const double nuj = -uj, nqj = -qj;
+            HouseholderUpdate<NPAD>::run(a, nuj, nqj, l, U, Q, col);
+        }
+    }
+    {
+        const double a11 = half_lane(a[1], 1, upper), a10 = half_lane(a[0], 1, upper), a00 = half_lane(a[0], 0, upper);
+        if (hl == 0) { L.de[(lane & 32) + 1] = make_double2(a11, a10 * a10); L.de[lane & 32] = make_double2(a00, 0.0); }
+    }
+    WSYNC();
+    // 32-way multisection per half on the Sturm sign changes (see sturm_largest_wave); the padded rows are zero
+    // eigenvalues, below every x of the bracket, so "all np eigenvalues below x" is the test in both halves.
+    double lo = (double)(dmax + 1) * (1.0 - 1e-13) - 1e-13;
+    double hi = (double)min(np_own, 2 * dmax) * (1.0 + 1e-13) + 1e-13;
+    const double2* de = L.de + (lane & 32);
+    for (int r = 0; r < rounds; ++r) {
+        const bool active = (hi - lo) > 1e-11 * hi;
+        if (ballot64(active) == 0) break;
+        const double w = (hi - lo) * (1.0 / 33.0);
+        const double x = lo + w * (double)(hl + 1);
+        double pm = 1.0, pc = de[0].x - x;
+        uint32_t bits = (uint32_t)__double2hiint(pc) >> 31;
+        int cnt = 0, fresh = 1;
+        auto term = [&](int i) {
+            const double2 t = de[i];
+            const double pn = fma(t.x - x, pc, -(t.y * pm));
+            bits = __builtin_amdgcn_alignbit(bits, (uint32_t)__double2hiint(pn), 31);
+            pm = pc;
+            pc = pn;
+        };
+        auto flush = [&]() {
+            cnt += __popc((bits ^ (bits >> 1)) & ((1u << fresh) - 1u));
+            fresh = 0;
+        };
+        int i = 1;
+        for (; i + 8 <= np; i += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) term(i + k);
+            fresh += 8;
+            if (fresh >= 17) flush();
+            if (i & 8) {
+                const int ex = __builtin_amdgcn_frexp_exp(fabs(pc) > fabs(pm) ? pc : pm);
+                pc = ldexp(pc, -ex);
+                pm = ldexp(pm, -ex);
+            }
+        }
+        for (; i < np; ++i) { term(i); ++fresh; }
+        flush();
+        const uint64_t all = ballot64(cnt >= np);
+        const uint32_t mine = upper ? (uint32_t)(all >> 32) : (uint32_t)all;
+        if (active) {
+            if (mine == 0) {
+                lo = lo + w * 32.0;                     // x of the half's last lane
+            } else {
+                const int t = __ffs((int)mine) - 1;
+                const double xl = lo + w * (double)t;   // x of lane t - 1 (t > 0)
+                hi = lo + w * (double)(t + 1);          // x of lane t, the same expression that lane evaluated
+                if (t > 0) lo = xl;
+            }
+        }
+    }
+    return 0.5 * (lo + hi);
+}
+
+// mu_max of one eigenproblem inside a wave, by the solver the step's solve launch would use for it: problems of
+// at most 32 vertices go through the two-per-wave code (alone, the upper half idle), so that the result does not
+// depend on the schedule; larger ones through the 64-lane solver.
+template <int NPAD, class LDS>
+__device__ __forceinline__ double mu_max_in_wave(uint64_t crow, int np, int lane, LDS& L, int rounds) {
+    if (np <= 32) {
+        const bool upper = lane >= 32;
+        return readlane_d(mu_max_pair_wave(upper ? 0u : (uint32_t)crow, np, upper ? 0 : np, lane, L, rounds + 2), 0);
+    }
+    if constexpr (NPAD > 32) return mu_max_compact_wave<NPAD>(crow, np, lane, L, rounds);
+    return 0.0;
+}
+
 // Second-smallest eigenvalue of L = D - A for the graph whose adjacency rows are
 // `row` (communication_graph.py:184-286; the reference calls LAPACK dsyevr through
 // scipy.linalg.eigh(subset_by_index=[0,1])).
@@ -764,7 +922,7 @@ __device__ __forceinline__ double lambda2_wave(uint64_t row, int n, int lane, Wa
     uint64_t crow;
     int np;
     if (lambda2_prepare(row, n, lane, L, lam, crow, np)) return lam;
-    return (double)n - mu_max_compact_wave<NPAD>(crow, np, lane, L, rounds);
+    return (double)n - mu_max_in_wave<NPAD>(crow, np, lane, L, rounds);
 }
 
 // ------------------------------------------------------------------ DBSCAN + centroids
@@ -1184,7 +1342,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 
     bool final_lam = lambda2_prepare(adj & ~jam, n, lane, L, lam, crow, np);
     if constexpr (FUSED > 0) {
         if (!final_lam) {
-            lam = (double)n - mu_max_compact_wave<FUSED>(crow, np, lane, L, P.lambda2_rounds);
+            lam = (double)n - mu_max_in_wave<FUSED>(crow, np, lane, L, P.lambda2_rounds);
             final_lam = true;
             np = 0;
         }
@@ -1252,6 +1410,7 @@ __global__ __launch_bounds__(1024) void solve_order_kernel(int E, MarlEnvState S
             at += cnt[k];
         }
         if (blockIdx.x == 0 && threadIdx.x == WAVE - 1) S.solve_hist[SOLVE_HIST_TOTAL] = incl;
+        if (blockIdx.x == 0 && threadIdx.x == WAVE / 2 - 1) S.solve_hist[SOLVE_HIST_TOTAL + 1] = incl;     // problems of more than 32 vertices
     }
     __syncthreads();
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1273,7 +1432,31 @@ __global__ __launch_bounds__(WAVE) void env_step_solve_kernel(MarlEnvParams P, M
     __shared__ SolveLds L;
     const int lane = threadIdx.x;
     const int total = S.solve_hist[SOLVE_HIST_TOTAL];
-    if ((int)blockIdx.x >= total) {
+    // the problems of more than 32 vertices take a wave each (blocks 0..nbig-1), the others share one in pairs
+    const int nbig = S.solve_hist[SOLVE_HIST_TOTAL + 1];
+    const int npairs = (total - nbig + 1) >> 1;
+    if ((int)blockIdx.x >= nbig && (int)blockIdx.x < nbig + npairs) {
+        const int k = nbig + 2 * ((int)blockIdx.x - nbig);
+        const int eA = S.solve_perm[k], eB = (k + 1 < total) ? S.solve_perm[k + 1] : -1;
+        const int npA = S.solve_np[eA], npB = (eB >= 0) ? S.solve_np[eB] : 0;      // sorted: npA >= npB
+        const bool upper = lane >= 32;
+        const int e = upper ? eB : eA, np_own = upper ? npB : npA, hl = lane & 31;
+        const uint32_t crow = (e >= 0 && hl < np_own) ? (uint32_t)S.solve_rows[(size_t)e * WAVE + hl] : 0u;
+        const double mu = mu_max_pair_wave(crow, npA, np_own, lane, L, P.lambda2_rounds + 2);
+        if (hl == 0 && e >= 0) {
+            const double lam = (double)P.N - mu;
+            const double* part = S.solve_partial + (size_t)e * 4;
+            const double lam0 = S.lambda2_initial[e];
+            double r1;
+            const double total_r = reward_total(P, lam, lam0, part[0], part[1], (float)part[2], part[3], r1);
+            finish_env(P, S, io, e, S.step_count[e], total_r, lam, lam0);
+#ifndef MARL_EXP_TIMING
+            if (io.reward_terms) io.reward_terms[(size_t)e * 5] = (float)r1;
+#endif
+        }
+        return;
+    }
+    if ((int)blockIdx.x >= nbig + npairs) {
         // the histogram has been consumed by the order kernel: the last block clears it for the next step
         // (bins only: the other blocks of this launch still read the total)
         if (blockIdx.x == gridDim.x - 1)
@@ -1853,7 +2036,7 @@ __device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int 
     WSYNC();
     if (np <= WAVE) {
         const uint64_t crow = (lane < np) ? L.xfer[lane * S] : 0ull;
-        return (double)n - mu_max_compact_wave<WAVE>(crow, np, lane, L, rounds);
+        return (double)n - mu_max_in_wave<WAVE>(crow, np, lane, L, rounds);
     }
     if (pending != nullptr && np <= TEAM_MAX_NP) {
         unsigned long long* out = reinterpret_cast<unsigned long long*>(As);
