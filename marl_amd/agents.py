@@ -239,25 +239,51 @@ class DeviceRolloutBuffer:
         return obs, actions, log_probs, adv, ret, val
 
 
+def _fragment_order(H: int, device):
+    """Index tables of the matrix-core layout marl_policy_act uses: unit[s, hl] = the hidden unit that a lane of
+    wave half hl holds in its s-th accumulator register (block s // 16, register s % 16)."""
+    s = torch.arange(H // 2, device=device)
+    b, v = s // 16, s % 16
+    hl = torch.arange(2, device=device)
+    return (32 * b + 8 * (v // 4) + (v % 4))[:, None] + 4 * hl[None, :]          # [H/2, 2]
+
+
 def pack_policy_weights(actor: "Actor", critic: "Critic") -> torch.Tensor:
     """Actor and critic parameters as the flat float32 buffer marl_policy_act reads (layout: include/marl_env.h).
-    The hidden-layer matrices are stored in groups of four output units, [H/4][H][4], so that the kernel's
-    scalar loads are contiguous."""
+    Matrices are stored as the A-operand fragments of v_mfma_f32_32x32x2: for output block bo and step s,
+    lane l carries W[32 bo + l % 32][k(s, l // 32)], where k is input 2 s + l // 32 for the first layer (the bias
+    as input 5) and the unit the lane's s-th accumulator register holds for the hidden layer and the heads."""
     H = actor.hidden_dim
-    if actor.num_bands != 4 or actor.obs_dim != 5 or critic.hidden_dim != H:
-        raise ValueError("marl_policy_act: obs_dim 5, 4 bands and equal hidden sizes only")
+    if actor.num_bands != 4 or actor.obs_dim != 5 or critic.hidden_dim != H or H % 32:
+        raise ValueError("marl_policy_act: obs_dim 5, 4 bands and equal hidden sizes (multiples of 32) only")
+    dev = actor.mu_head.weight.device
+    NB, NS = H // 32, H // 2
+    lane = torch.arange(64, device=dev)
+    row, half = lane % 32, lane // 32
+    unit = _fragment_order(H, dev)                                                # [NS, 2]
 
-    def quad(w):                       # [H, H] (out, in) -> [H/4][H][4]
-        return w.detach().reshape(H // 4, 4, H).permute(0, 2, 1).reshape(-1)
+    def first(w, b):                   # [H, 5], [H] -> [NB][3][64]
+        we = torch.cat([w.detach().float(), b.detach().float()[:, None]], 1)      # [H, 6]
+        rows = (32 * torch.arange(NB, device=dev))[:, None, None] + row[None, None, :]
+        cols = (2 * torch.arange(3, device=dev))[None, :, None] + half[None, None, :]
+        return we[rows, cols].reshape(-1)
+
+    def hidden(w, blocks):             # [32 * blocks, H] (out, in) -> [blocks][NS/4][64][4]
+        w = w.detach().float()
+        rows = (32 * torch.arange(blocks, device=dev))[:, None, None] + row[None, None, :]        # [blocks, 1, 64]
+        cols = unit[:, half][None, :, :]                                                            # [1, NS, 64]
+        f = w[rows, cols]                                                                           # [blocks, NS, 64]
+        return f.reshape(blocks, NS // 4, 4, 64).permute(0, 1, 3, 2).reshape(-1)
 
     t, n = actor.trunk, critic.network
-    heads_w = torch.cat([actor.mu_head.weight, actor.log_std_head.weight, actor.band_head.weight], 0).detach()    # [8, H]
+    heads_w = torch.zeros(32, H, device=dev)
+    heads_w[:8] = torch.cat([actor.mu_head.weight, actor.log_std_head.weight, actor.band_head.weight], 0).detach()
     heads_b = torch.cat([actor.mu_head.bias, actor.log_std_head.bias, actor.band_head.bias], 0).detach()
-    parts = [t[0].weight.detach().reshape(-1), t[0].bias.detach(), t[1].weight.detach(), t[1].bias.detach(),
-             quad(t[3].weight), t[3].bias.detach(), t[4].weight.detach(), t[4].bias.detach(),
-             heads_w.t().reshape(-1), heads_b,
-             n[0].weight.detach().reshape(-1), n[0].bias.detach(), quad(n[2].weight), n[2].bias.detach(),
-             n[4].weight.detach().reshape(-1), n[4].bias.detach()]
+    parts = [first(t[0].weight, t[0].bias), t[1].weight.detach(), t[1].bias.detach(),
+             hidden(t[3].weight, NB), t[3].bias.detach(), t[4].weight.detach(), t[4].bias.detach(),
+             hidden(heads_w, 1), heads_b,
+             first(n[0].weight, n[0].bias), hidden(n[2].weight, NB), n[2].bias.detach(),
+             n[4].weight.detach().reshape(-1), n[4].bias.detach(), torch.zeros(3, device=dev)]
     return torch.cat([p.float().reshape(-1) for p in parts]).contiguous()
 
 

@@ -5,11 +5,19 @@
 // Critic.forward_pooled on the mean-pooled observation (agents/critic.py:71-134).  The results are written
 // where the caller points: the action / log-prob / value slots of a device rollout buffer.
 //
-// One lane = one agent (actor part) or one env (critic part), so LayerNorm and the heads are lane-local and
-// every weight is wave-uniform: weights come through the scalar cache as SGPR operands of the multiply-adds,
-// two output units per instruction, two independent accumulator chains (the hidden-layer matrix is stored
-// interleaved in groups of four output units for that).  float32
-// throughout, like the networks it mirrors.
+// The three layers of each network are dense contractions and run on the matrix cores in float32
+// (v_mfma_f32_32x32x2): hidden units on the rows of the product, 32 agents (or envs) on its columns,
+//     D[unit][agent] += W[unit][k] * x[k][agent].
+// With that orientation a lane owns ONE agent (column lane % 32) and half of its hidden units
+// (unit u is held by half hl = (u / 4) % 2 of the wave: the accumulator layout of the instruction), so
+//   * LayerNorm and ReLU are lane-local plus one exchange with the lane 32 away,
+//   * the accumulators of one layer are, register for register, the B operand of the next: the k-th step of the
+//     next contraction takes the k-th unit a lane owns, and the weights are stored pre-permuted to match
+//     (host side: pack_policy_weights), one 16-byte LDS read per four steps,
+//   * the head outputs land in the first registers of the lanes (means and log-stds in the lower half of the wave,
+//     band logits in the upper half).
+// A workgroup (8 waves) keeps one network's permuted weights in LDS and walks over tiles of 32 agents; the
+// grid is one workgroup per CU, split between actor and critic in proportion to their work.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -20,207 +28,297 @@
 namespace {
 
 using namespace marl_rng;
-typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int WAVE = 64;
 constexpr int OBS = MARL_OBS_DIM;
-constexpr int HEADS = 8;                 // mu_x, mu_y, log_std_x, log_std_y, 4 band logits
+constexpr int POLICY_THREADS = 512;
+constexpr int POLICY_WAVES = POLICY_THREADS / WAVE;
+
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
 
 // Offsets (in floats) of the packed weight buffer, see marl_policy_weight_count in marl_env.h.
 template <int H>
 struct Pack {
-    static constexpr int a_w1 = 0;                         // [H][5]
-    static constexpr int a_b1 = a_w1 + H * OBS;            // [H]
-    static constexpr int a_g1 = a_b1 + H;                  // LayerNorm 1 weight
-    static constexpr int a_e1 = a_g1 + H;                  // LayerNorm 1 bias
-    static constexpr int a_w2 = a_e1 + H;                  // [H/4][H][4]: (W2[4t][k], W2[4t+1][k], W2[4t+2][k], W2[4t+3][k])
-    static constexpr int a_b2 = a_w2 + H * H;
+    static constexpr int NB = H / 32, NS = H / 2;
+    static constexpr int a_f1 = 0;                          // [NB][3][64]     layer-1 fragments (bias as input 5)
+    static constexpr int a_g1 = a_f1 + NB * 3 * 64;         // [H] LayerNorm 1 weight
+    static constexpr int a_e1 = a_g1 + H;                   // [H] LayerNorm 1 bias
+    static constexpr int a_f2 = a_e1 + H;                   // [NB][NS/4][64][4] layer-2 fragments
+    static constexpr int a_b2 = a_f2 + H * H;               // [H]
     static constexpr int a_g2 = a_b2 + H;
     static constexpr int a_e2 = a_g2 + H;
-    static constexpr int a_wh = a_e2 + H;                  // [H][8]: column j of the stacked head matrix
-    static constexpr int a_bh = a_wh + H * HEADS;          // [8]
-    static constexpr int c_w1 = a_bh + HEADS;              // critic [H][5]
-    static constexpr int c_b1 = c_w1 + H * OBS;
-    static constexpr int c_w2 = c_b1 + H;                  // [H/4][H][4]
-    static constexpr int c_b2 = c_w2 + H * H;
-    static constexpr int c_w3 = c_b2 + H;                  // [H]
-    static constexpr int c_b3 = c_w3 + H;                  // [1]
-    static constexpr int total = c_b3 + 1;
+    static constexpr int a_fh = a_e2 + H;                   // [NS/4][64][4]   head fragments (rows 8..31 zero)
+    static constexpr int a_bh = a_fh + NS * 64;             // [8]
+    static constexpr int a_end = a_bh + 8;
+    static constexpr int c_f1 = a_end;                      // critic [NB][3][64]
+    static constexpr int c_f2 = c_f1 + NB * 3 * 64;         // [NB][NS/4][64][4]
+    static constexpr int c_b2 = c_f2 + H * H;               // [H]
+    static constexpr int c_w3 = c_b2 + H;                   // [H]
+    static constexpr int c_b3 = c_w3 + H;                   // [1] + 3 pad
+    static constexpr int total = c_b3 + 4;
+    static constexpr int lds_floats = a_end > total - c_f1 ? a_end : total - c_f1;
 };
 
-__device__ __forceinline__ float2v fma2(float2v a, float2v b, float2v c) { return __builtin_elementwise_fma(a, b, c); }
-
-// Four units of the hidden layer at once: (a0, a1) += W2[4t .. 4t+3][:] . h, with h held as H/2 register pairs
-// whose halves are selected by the instruction (no copies), weights wave-uniform and contiguous.
-template <int H>
-__device__ __forceinline__ void four_units(const float* __restrict__ w4, float2v (&hp)[H / 2], float2v& a0, float2v& a1) {
-    const float2v* __restrict__ w = reinterpret_cast<const float2v*>(w4);
-#pragma unroll
-    for (int kp = 0; kp < H / 2; ++kp) {
-        // opaque redefinition inside the caller's loop: keeps the broadcasts below from being hoisted out of it as
-        // H extra register pairs; as operands of the multiply-add they cost nothing (op_sel picks the half)
-        asm volatile("" : "+v"(hp[kp]));
-        const float2v lo = __builtin_shufflevector(hp[kp], hp[kp], 0, 0), hi = __builtin_shufflevector(hp[kp], hp[kp], 1, 1);
-        a0 = fma2(w[4 * kp], lo, a0);
-        a1 = fma2(w[4 * kp + 1], lo, a1);
-        a0 = fma2(w[4 * kp + 2], hi, a0);
-        a1 = fma2(w[4 * kp + 3], hi, a1);
-    }
+__device__ __forceinline__ floatx16 mfma(float a, float b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// h[j] = b[j] + W[j][:] . o   for the 5 observation features (weights wave-uniform)
-template <int H>
-__device__ __forceinline__ void first_layer(const float* __restrict__ w, const float* __restrict__ b,
-                                            const float (&o)[OBS], float (&h)[H]) {
-#pragma unroll
-    for (int j = 0; j < H; ++j) {
-        float x = b[j];
-#pragma unroll
-        for (int k = 0; k < OBS; ++k) x = fmaf(w[j * OBS + k], o[k], x);
-        h[j] = x;
-    }
+// Keeps the compiler from hoisting every LDS read of an unrolled loop to its top (which costs more registers than
+// a wave has): reads are not moved across it.
+#define LDS_FENCE() asm volatile("" ::: "memory")
+
+// The unit a lane of half `hl` holds in register v of accumulator block b.
+__device__ __forceinline__ constexpr int unit_of(int b, int v, int hl) { return 32 * b + 8 * (v / 4) + 4 * hl + (v % 4); }
+
+// Per-unit vector (bias, LayerNorm weight ...) gathered into the lane's register order: 16-byte reads of the four
+// consecutive units that registers 4q .. 4q+3 of a block hold.
+template <int NB>
+__device__ __forceinline__ void unit_vector(const float* __restrict__ lds_vec, int hl, floatx16 (&out)[NB]) {
+    static_for<0, NB>([&](auto bb) {
+        constexpr int b = decltype(bb)::value;
+        static_for<0, 4>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            const float4 t = *reinterpret_cast<const float4*>(lds_vec + 32 * b + 8 * q + 4 * hl);
+            out[b][4 * q] = t.x; out[b][4 * q + 1] = t.y; out[b][4 * q + 2] = t.z; out[b][4 * q + 3] = t.w;
+        });
+    });
+}
+
+// x[unit] over the H units of the lane's agent -> relu(LayerNorm(x) * g + e) (eps 1e-5, biased variance), in place.
+template <int NB>
+__device__ __forceinline__ void layer_norm_relu(floatx16 (&x)[NB], const float* __restrict__ g, const float* __restrict__ e, int hl) {
+    constexpr int H = NB * 32;
+    float sum = 0.0f;
+    static_for<0, NB>([&](auto bb) { static_for<0, 16>([&](auto vv) { sum += x[decltype(bb)::value][decltype(vv)::value]; }); });
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / H);
+    float var = 0.0f;
+    static_for<0, NB>([&](auto bb) {
+        static_for<0, 16>([&](auto vv) {
+            const float d = x[decltype(bb)::value][decltype(vv)::value] - mean;
+            var = fmaf(d, d, var);
+        });
+    });
+    var += __shfl_xor(var, 32);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / H) + 1e-5f);
+    static_for<0, NB>([&](auto bb) {
+        constexpr int b = decltype(bb)::value;
+        static_for<0, 4>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            const float4 gq = *reinterpret_cast<const float4*>(g + 32 * b + 8 * q + 4 * hl);
+            const float4 eq = *reinterpret_cast<const float4*>(e + 32 * b + 8 * q + 4 * hl);
+            x[b][4 * q] = fmaxf(fmaf((x[b][4 * q] - mean) * rstd, gq.x, eq.x), 0.0f);
+            x[b][4 * q + 1] = fmaxf(fmaf((x[b][4 * q + 1] - mean) * rstd, gq.y, eq.y), 0.0f);
+            x[b][4 * q + 2] = fmaxf(fmaf((x[b][4 * q + 2] - mean) * rstd, gq.z, eq.z), 0.0f);
+            x[b][4 * q + 3] = fmaxf(fmaf((x[b][4 * q + 3] - mean) * rstd, gq.w, eq.w), 0.0f);
+            LDS_FENCE();
+        });
+    });
+}
+
+// Layer 1: D[unit][agent] = W1[unit][0..4] . obs + b1[unit] (the bias rides as input 5 = 1).  x0..x2 = the lane's
+// B operands of the three steps (inputs 2s + hl).
+template <int NB>
+__device__ __forceinline__ void first_layer(const float* __restrict__ f1, int lane, float x0, float x1, float x2, floatx16 (&acc)[NB]) {
+    static_for<0, NB>([&](auto bb) {
+        constexpr int b = decltype(bb)::value;
+        floatx16 c = {0};
+        c = mfma(f1[(b * 3 + 0) * 64 + lane], x0, c);
+        c = mfma(f1[(b * 3 + 1) * 64 + lane], x1, c);
+        c = mfma(f1[(b * 3 + 2) * 64 + lane], x2, c);
+        acc[b] = c;
+    });
+}
+
+// Layer 2: acc[bo] (initialised with the bias) += W2 . y, y = the lane's accumulators of the layer before.
+template <int NB>
+__device__ __forceinline__ void hidden_layer(const float* __restrict__ f2, int lane, const floatx16 (&y)[NB], floatx16 (&acc)[NB]) {
+    constexpr int NS = NB * 16;
+    float4 w[NB], wn[NB];
+    static_for<0, NB>([&](auto bb) {
+        constexpr int bo = decltype(bb)::value;
+        w[bo] = *reinterpret_cast<const float4*>(f2 + ((size_t)(bo * (NS / 4)) * 64 + lane) * 4);
+    });
+    static_for<0, NS / 4>([&](auto ss) {
+        constexpr int s4 = decltype(ss)::value;
+        if constexpr (s4 + 1 < NS / 4) {                         // the next group's weights travel while this group computes
+            static_for<0, NB>([&](auto bb) {
+                constexpr int bo = decltype(bb)::value;
+                wn[bo] = *reinterpret_cast<const float4*>(f2 + ((size_t)(bo * (NS / 4) + s4 + 1) * 64 + lane) * 4);
+            });
+        }
+        LDS_FENCE();
+        static_for<0, 4>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            constexpr int s = 4 * s4 + q;
+            const float yk = y[s / 16][s % 16];
+            static_for<0, NB>([&](auto bb) {
+                constexpr int bo = decltype(bb)::value;
+                const float wk = q == 0 ? w[bo].x : (q == 1 ? w[bo].y : (q == 2 ? w[bo].z : w[bo].w));
+                acc[bo] = mfma(wk, yk, acc[bo]);
+            });
+        });
+        if constexpr (s4 + 1 < NS / 4) static_for<0, NB>([&](auto bb) { w[decltype(bb)::value] = wn[decltype(bb)::value]; });
+    });
 }
 
 template <int H>
-__global__ __launch_bounds__(WAVE) void policy_act_kernel(const float* __restrict__ wts, const float* __restrict__ obs,
-                                                          const int32_t* __restrict__ tick, float* __restrict__ actions,
-                                                          float* __restrict__ log_probs, float* __restrict__ values,
-                                                          int E, int M, float v_max, float ls_min, float ls_max,
-                                                          uint64_t seed, uint64_t env_offset, uint32_t call,
-                                                          int deterministic, int actor_blocks) {
+__global__ __launch_bounds__(POLICY_THREADS) void policy_act_kernel(const float* __restrict__ wts, const float* __restrict__ obs,
+                                                                     const int32_t* __restrict__ tick, float* __restrict__ actions,
+                                                                     float* __restrict__ log_probs, float* __restrict__ values,
+                                                                     int E, int M, float v_max, float ls_min, float ls_max,
+                                                                     uint64_t seed, uint64_t env_offset, uint32_t call,
+                                                                     int deterministic, int actor_blocks) {
     using P = Pack<H>;
-    __shared__ float h2s[H * WAVE];                   // hidden layer 2 before its LayerNorm: [unit][lane]
-    const int lane = threadIdx.x;
-    if ((int)blockIdx.x < actor_blocks) {
+    constexpr int NB = P::NB, NS = P::NS;
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int hl = lane >> 5, j = lane & 31;
+    const bool actor = (int)blockIdx.x < actor_blocks;
+    {   // this network's fragments -> LDS
+        const float4* src = reinterpret_cast<const float4*>(wts + (actor ? 0 : P::c_f1));
+        const int n4 = (actor ? P::a_end : P::total - P::c_f1) / 4;
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int i = tid; i < n4; i += POLICY_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (actor) {
         const int rows = E * M;
-        const int row = blockIdx.x * WAVE + lane;
-        const bool valid = row < rows;
-        const int r = valid ? row : rows - 1;
-        float o[OBS];
+        const int tiles = (rows + 31) / 32;
+        for (int tile = blockIdx.x * POLICY_WAVES + wave; tile < tiles; tile += actor_blocks * POLICY_WAVES) {
+            const int row = tile * 32 + j;
+            const bool valid = row < rows;
+            const int r = valid ? row : rows - 1;
+            const float* o = obs + (size_t)r * OBS;
+            const float x0 = o[hl], x1 = o[2 + hl], x2 = hl ? 1.0f : o[4];
+            floatx16 y1[NB], y2[NB];
+            first_layer<NB>(lds + P::a_f1, lane, x0, x1, x2, y1);
+            layer_norm_relu<NB>(y1, lds + P::a_g1, lds + P::a_e1, hl);
+            unit_vector<NB>(lds + P::a_b2, hl, y2);
+            hidden_layer<NB>(lds + P::a_f2, lane, y1, y2);
+            layer_norm_relu<NB>(y2, lds + P::a_g2, lds + P::a_e2, hl);
+            // heads: two accumulators (even / odd steps) so that consecutive instructions do not depend on each other
+            floatx16 h0 = {0}, h1 = {0};
+            {
+                const float4 bh = *reinterpret_cast<const float4*>(lds + P::a_bh + 4 * hl);
+                h0[0] = bh.x; h0[1] = bh.y; h0[2] = bh.z; h0[3] = bh.w;
+            }
+            static_for<0, NS / 4>([&](auto ss) {
+                constexpr int s4 = decltype(ss)::value;
+                const float4 w = *reinterpret_cast<const float4*>(lds + P::a_fh + ((size_t)s4 * 64 + lane) * 4);
+                h0 = mfma(w.x, y2[(4 * s4) / 16][(4 * s4) % 16], h0);
+                h1 = mfma(w.y, y2[(4 * s4 + 1) / 16][(4 * s4 + 1) % 16], h1);
+                h0 = mfma(w.z, y2[(4 * s4 + 2) / 16][(4 * s4 + 2) % 16], h0);
+                h1 = mfma(w.w, y2[(4 * s4 + 3) / 16][(4 * s4 + 3) % 16], h1);
+                LDS_FENCE();
+            });
+            // this lane: heads 4 hl .. 4 hl + 3 of its agent; the partner (lane ^ 32) holds the other four
+            float mine[4], other[4];
 #pragma unroll
-        for (int k = 0; k < OBS; ++k) o[k] = obs[(size_t)r * OBS + k];
-        float h[H];
-        first_layer<H>(wts + P::a_w1, wts + P::a_b1, o, h);
-        {   // LayerNorm (eps 1e-5, biased variance) + ReLU
-            float mean = 0.0f;
+            for (int q = 0; q < 4; ++q) { mine[q] = h0[q] + h1[q]; other[q] = __shfl_xor(mine[q], 32); }
+            const float mu0 = hl ? other[0] : mine[0], mu1 = hl ? other[1] : mine[1];
+            const float rl0 = hl ? other[2] : mine[2], rl1 = hl ? other[3] : mine[3];
+            float lg[4];
 #pragma unroll
-            for (int j = 0; j < H; ++j) mean += h[j];
-            mean *= 1.0f / H;
-            float var = 0.0f;
+            for (int q = 0; q < 4; ++q) lg[q] = hl ? mine[q] : other[q];
+            // distributions (actor.py:160-196); both halves compute, the lower half writes
+            const float ls0 = fminf(fmaxf(rl0, ls_min), ls_max), ls1 = fminf(fmaxf(rl1, ls_min), ls_max);
+            const float sd0 = expf(ls0), sd1 = expf(ls1);
+            const float lmax = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+            float ex[4], esum = 0.0f;
 #pragma unroll
-            for (int j = 0; j < H; ++j) { const float d = h[j] - mean; var = fmaf(d, d, var); }
-            const float rstd = 1.0f / sqrtf(var * (1.0f / H) + 1e-5f);
+            for (int q = 0; q < 4; ++q) { ex[q] = expf(lg[q] - lmax); esum += ex[q]; }
+            const float lse = lmax + logf(esum);
+            float vx, vy;
+            int band;
+            if (deterministic) {
+                vx = mu0; vy = mu1;
+                band = 0;
 #pragma unroll
-            for (int j = 0; j < H; ++j)
-                h[j] = fmaxf(fmaf((h[j] - mean) * rstd, wts[P::a_g1 + j], wts[P::a_e1 + j]), 0.0f);
+                for (int q = 1; q < 4; ++q) if (lg[q] > lg[band]) band = q;          // first maximum, as argmax
+            } else {
+                const int e = r / M, a = r - e * M;
+                const uint64_t genv = env_offset + e;
+                uint32_t rn[4];
+                philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)a << 8) ^ STREAM_POLICY,
+                           tick ? (uint32_t)tick[e] : 0u, call, (uint32_t)seed, (uint32_t)(seed >> 32), rn);
+                // Box-Muller for the two velocity draws, inverse CDF for the band
+                const float u1 = ((float)(rn[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                const float u2 = ((float)(rn[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                const float rad = sqrtf(-2.0f * logf(u1));
+                float sn, cs;
+                sincosf(6.2831853071795865f * u2, &sn, &cs);
+                vx = fmaf(sd0, rad * cs, mu0);
+                vy = fmaf(sd1, rad * sn, mu1);
+                const float u3 = ((float)(rn[2] >> 8) + 0.5f) * (1.0f / 16777216.0f) * esum;
+                band = 3;
+                float cum = ex[0];
+                if (u3 < cum) band = 0;
+                else { cum += ex[1]; if (u3 < cum) band = 1; else { cum += ex[2]; if (u3 < cum) band = 2; } }
+            }
+            // Normal.log_prob of the unclamped draw, summed over the two components, + Categorical.log_prob
+            const float z0 = (vx - mu0) / sd0, z1 = (vy - mu1) / sd1;
+            const float lp = (-0.5f * z0 * z0 - ls0 - 0.91893853320467274f) + (-0.5f * z1 * z1 - ls1 - 0.91893853320467274f)
+                             + (lg[band] - lse);
+            if (valid && hl == 0) {
+                float* out = actions + (size_t)row * 3;
+                out[0] = fminf(fmaxf(vx, -v_max), v_max);
+                out[1] = fminf(fmaxf(vy, -v_max), v_max);
+                out[2] = (float)band;
+                log_probs[row] = lp;
+            }
         }
-        float2v hp[H / 2];
-#pragma unroll
-        for (int j = 0; j < H / 2; ++j) {
-            hp[j] = (float2v){h[2 * j], h[2 * j + 1]};
-            asm volatile("" : "+v"(hp[j]));         // keep the pair as one 64-bit value: its halves are picked by op_sel
+    } else {
+        const int nblocks = gridDim.x - actor_blocks;
+        const int tiles = (E + 31) / 32;
+        // the critic's part of the buffer sits at the start of LDS: same offsets relative to c_f1
+        const float* cf1 = lds;
+        const float* cf2 = lds + (P::c_f2 - P::c_f1);
+        const float* cb2 = lds + (P::c_b2 - P::c_f1);
+        const float* cw3 = lds + (P::c_w3 - P::c_f1);
+        const float cb3 = lds[P::c_b3 - P::c_f1];
+        for (int tile = ((int)blockIdx.x - actor_blocks) * POLICY_WAVES + wave; tile < tiles; tile += nblocks * POLICY_WAVES) {
+            const int env = tile * 32 + j;
+            const bool valid = env < E;
+            const int e = valid ? env : E - 1;
+            float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;                 // inputs hl, 2 + hl, 4 of the mean-pooled observation
+            for (int m = 0; m < M; ++m) {
+                const float* o = obs + ((size_t)e * M + m) * OBS;
+                p0 += o[hl]; p1 += o[2 + hl]; p2 += o[4];
+            }
+            const float x0 = p0 / (float)M, x1 = p1 / (float)M, x2 = hl ? 1.0f : p2 / (float)M;
+            floatx16 y1[NB], y2[NB];
+            first_layer<NB>(cf1, lane, x0, x1, x2, y1);
+            static_for<0, NB>([&](auto bb) { static_for<0, 16>([&](auto vv) {
+                y1[decltype(bb)::value][decltype(vv)::value] = fmaxf(y1[decltype(bb)::value][decltype(vv)::value], 0.0f); }); });
+            unit_vector<NB>(cb2, hl, y2);
+            hidden_layer<NB>(cf2, lane, y1, y2);
+            float v = 0.0f;
+            static_for<0, NB>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                static_for<0, 4>([&](auto qq) {
+                    constexpr int q = decltype(qq)::value;
+                    const float4 wq = *reinterpret_cast<const float4*>(cw3 + 32 * b + 8 * q + 4 * hl);
+                    v = fmaf(wq.x, fmaxf(y2[b][4 * q], 0.0f), v);
+                    v = fmaf(wq.y, fmaxf(y2[b][4 * q + 1], 0.0f), v);
+                    v = fmaf(wq.z, fmaxf(y2[b][4 * q + 2], 0.0f), v);
+                    v = fmaf(wq.w, fmaxf(y2[b][4 * q + 3], 0.0f), v);
+                    LDS_FENCE();
+                });
+            });
+            v += __shfl_xor(v, 32);
+            if (valid && hl == 0) values[env] = v + cb3;
         }
-        float sum2 = 0.0f;
-        for (int t = 0; t < H / 4; ++t) {            // four hidden units per trip; the k loop is straight-line code
-            float2v a0 = {wts[P::a_b2 + 4 * t], wts[P::a_b2 + 4 * t + 1]}, a1 = {wts[P::a_b2 + 4 * t + 2], wts[P::a_b2 + 4 * t + 3]};
-            four_units<H>(wts + P::a_w2 + (size_t)t * H * 4, hp, a0, a1);
-            h2s[(4 * t) * WAVE + lane] = a0.x;
-            h2s[(4 * t + 1) * WAVE + lane] = a0.y;
-            h2s[(4 * t + 2) * WAVE + lane] = a1.x;
-            h2s[(4 * t + 3) * WAVE + lane] = a1.y;
-            sum2 += (a0.x + a0.y) + (a1.x + a1.y);
-        }
-        const float mean2 = sum2 * (1.0f / H);
-        float var2 = 0.0f;
-        for (int j = 0; j < H; ++j) { const float d = h2s[j * WAVE + lane] - mean2; var2 = fmaf(d, d, var2); }
-        const float rstd2 = 1.0f / sqrtf(var2 * (1.0f / H) + 1e-5f);
-        float head[HEADS];
-#pragma unroll
-        for (int q = 0; q < HEADS; ++q) head[q] = wts[P::a_bh + q];
-        for (int j = 0; j < H; ++j) {
-            const float y = fmaxf(fmaf((h2s[j * WAVE + lane] - mean2) * rstd2, wts[P::a_g2 + j], wts[P::a_e2 + j]), 0.0f);
-#pragma unroll
-            for (int q = 0; q < HEADS; ++q) head[q] = fmaf(wts[P::a_wh + j * HEADS + q], y, head[q]);
-        }
-        // distributions (actor.py:160-196)
-        const float ls0 = fminf(fmaxf(head[2], ls_min), ls_max), ls1 = fminf(fmaxf(head[3], ls_min), ls_max);
-        const float sd0 = expf(ls0), sd1 = expf(ls1);
-        float lmax = fmaxf(fmaxf(head[4], head[5]), fmaxf(head[6], head[7]));
-        float ex[4], esum = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { ex[q] = expf(head[4 + q] - lmax); esum += ex[q]; }
-        const float lse = lmax + logf(esum);
-        float vx, vy;
-        int band;
-        if (deterministic) {
-            vx = head[0]; vy = head[1];
-            band = 0;
-#pragma unroll
-            for (int q = 1; q < 4; ++q) if (head[4 + q] > head[4 + band]) band = q;      // first maximum, as argmax
-        } else {
-            const int e = r / M, j = r - e * M;
-            const uint64_t genv = env_offset + e;
-            uint32_t rn[4];
-            philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ ((uint32_t)j << 8) ^ STREAM_POLICY,
-                       tick ? (uint32_t)tick[e] : 0u, call, (uint32_t)seed, (uint32_t)(seed >> 32), rn);
-            // Box-Muller for the two velocity draws, inverse CDF for the band
-            const float u1 = ((float)(rn[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-            const float u2 = ((float)(rn[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-            const float rad = sqrtf(-2.0f * logf(u1));
-            float sn, cs;
-            sincosf(6.2831853071795865f * u2, &sn, &cs);
-            vx = fmaf(sd0, rad * cs, head[0]);
-            vy = fmaf(sd1, rad * sn, head[1]);
-            const float u3 = ((float)(rn[2] >> 8) + 0.5f) * (1.0f / 16777216.0f) * esum;
-            band = 3;
-            float cum = ex[0];
-            if (u3 < cum) band = 0;
-            else { cum += ex[1]; if (u3 < cum) band = 1; else { cum += ex[2]; if (u3 < cum) band = 2; } }
-        }
-        // Normal.log_prob of the unclamped draw, summed over the two components, + Categorical.log_prob
-        const float z0 = (vx - head[0]) / sd0, z1 = (vy - head[1]) / sd1;
-        const float lp = (-0.5f * z0 * z0 - ls0 - 0.91893853320467274f) + (-0.5f * z1 * z1 - ls1 - 0.91893853320467274f)
-                         + (head[4 + band] - lse);
-        if (valid) {
-            float* a = actions + (size_t)row * 3;
-            a[0] = fminf(fmaxf(vx, -v_max), v_max);
-            a[1] = fminf(fmaxf(vy, -v_max), v_max);
-            a[2] = (float)band;
-            log_probs[row] = lp;
-        }
-    } else if (values != nullptr) {
-        const int env = ((int)blockIdx.x - actor_blocks) * WAVE + lane;
-        const bool valid = env < E;
-        const int e = valid ? env : E - 1;
-        float o[OBS];
-#pragma unroll
-        for (int k = 0; k < OBS; ++k) o[k] = 0.0f;
-        for (int m = 0; m < M; ++m)
-#pragma unroll
-            for (int k = 0; k < OBS; ++k) o[k] += obs[((size_t)e * M + m) * OBS + k];
-#pragma unroll
-        for (int k = 0; k < OBS; ++k) o[k] = o[k] / (float)M;              // obs.mean(dim=1)
-        float h[H];
-        first_layer<H>(wts + P::c_w1, wts + P::c_b1, o, h);
-#pragma unroll
-        for (int j = 0; j < H; ++j) h[j] = fmaxf(h[j], 0.0f);
-        float2v hp[H / 2];
-#pragma unroll
-        for (int j = 0; j < H / 2; ++j) {
-            hp[j] = (float2v){h[2 * j], h[2 * j + 1]};
-            asm volatile("" : "+v"(hp[j]));         // keep the pair as one 64-bit value: its halves are picked by op_sel
-        }
-        float v = wts[P::c_b3];
-        for (int t = 0; t < H / 4; ++t) {
-            float2v a0 = {wts[P::c_b2 + 4 * t], wts[P::c_b2 + 4 * t + 1]}, a1 = {wts[P::c_b2 + 4 * t + 2], wts[P::c_b2 + 4 * t + 3]};
-            four_units<H>(wts + P::c_w2 + (size_t)t * H * 4, hp, a0, a1);
-            v = fmaf(wts[P::c_w3 + 4 * t], fmaxf(a0.x, 0.0f), v);
-            v = fmaf(wts[P::c_w3 + 4 * t + 1], fmaxf(a0.y, 0.0f), v);
-            v = fmaf(wts[P::c_w3 + 4 * t + 2], fmaxf(a1.x, 0.0f), v);
-            v = fmaf(wts[P::c_w3 + 4 * t + 3], fmaxf(a1.y, 0.0f), v);
-        }
-        if (valid) values[env] = v;
     }
 }
+
+int g_cu_count = 0;
 
 }  // namespace
 
@@ -242,20 +340,43 @@ int marl_policy_act(int32_t E, int32_t M, int32_t hidden, float v_max, float log
     if (io->weights == nullptr || io->obs == nullptr || io->actions == nullptr || io->log_probs == nullptr)
         return MARL_EINVAL;
     if ((long long)E * M > (1ll << 30)) return MARL_EUNSUPPORTED;
-    const int actor_blocks = (int)(((long long)E * M + WAVE - 1) / WAVE);
-    const int critic_blocks = io->values ? (E + WAVE - 1) / WAVE : 0;
-    const dim3 grid(actor_blocks + critic_blocks);
-#define MARL_LAUNCH_POLICY(HH)                                                                                     \
-    hipLaunchKernelGGL(policy_act_kernel<HH>, grid, dim3(WAVE), 0, (hipStream_t)stream, io->weights, io->obs,       \
-                       io->tick, io->actions, io->log_probs, io->values, (int)E, (int)M, v_max, log_std_min,        \
-                       log_std_max, io->seed, io->env_offset, io->call, (int)io->deterministic, actor_blocks)
-    switch (hidden) {
-        case 64: MARL_LAUNCH_POLICY(64); break;
-        case 128: MARL_LAUNCH_POLICY(128); break;
-        default: return MARL_EUNSUPPORTED;
+    if (hidden != 64 && hidden != 128) return MARL_EUNSUPPORTED;
+    if (g_cu_count == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+        g_cu_count = cus;
     }
+    // one workgroup per CU; the critic gets its share of them (tiles x matrix instructions per tile)
+    const long long ta = ((long long)E * M + 31) / 32, tc = io->values ? (E + 31) / 32 : 0;
+    const double wa = (double)ta * (hidden / 32 * 3 + hidden / 32 * hidden / 2 + hidden / 2);
+    const double wc = (double)tc * (hidden / 32 * 3 + hidden / 32 * hidden / 2);
+    int grid = g_cu_count;
+    if (ta + tc < (long long)grid * POLICY_WAVES) grid = (int)((ta + tc + POLICY_WAVES - 1) / POLICY_WAVES) + (tc ? 1 : 0);
+    int critic_blocks = tc ? (int)(grid * wc / (wa + wc) + 0.5) : 0;
+    if (tc && critic_blocks < 1) critic_blocks = 1;
+    if (critic_blocks >= grid) critic_blocks = grid - 1;
+    if (grid < 1 + (tc ? 1 : 0)) { grid = 1 + (tc ? 1 : 0); critic_blocks = tc ? 1 : 0; }
+    const int actor_blocks = grid - critic_blocks;
+    hipError_t err = hipSuccess;
+#define MARL_LAUNCH_POLICY(HH)                                                                                     \
+    do {                                                                                                            \
+        static bool attr_set = false;                                                                               \
+        const size_t lds_bytes = (size_t)Pack<HH>::lds_floats * sizeof(float);                                      \
+        if (!attr_set) {                                                                                            \
+            err = hipFuncSetAttribute((const void*)policy_act_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)lds_bytes);                                                              \
+            attr_set = err == hipSuccess;                                                                           \
+        }                                                                                                           \
+        if (err == hipSuccess)                                                                                      \
+            hipLaunchKernelGGL(policy_act_kernel<HH>, dim3(grid), dim3(POLICY_THREADS), lds_bytes, (hipStream_t)stream, \
+                               io->weights, io->obs, io->tick, io->actions, io->log_probs, io->values, (int)E, (int)M, \
+                               v_max, log_std_min, log_std_max, io->seed, io->env_offset, io->call,                 \
+                               (int)io->deterministic, actor_blocks);                                               \
+    } while (0)
+    if (hidden == 64) MARL_LAUNCH_POLICY(64); else MARL_LAUNCH_POLICY(128);
 #undef MARL_LAUNCH_POLICY
-    const hipError_t err = hipGetLastError();
+    if (err == hipSuccess) err = hipGetLastError();
     if (err == hipSuccess) return MARL_OK;
     marl_note_hip_error((int)err);
     return MARL_EHIP;
