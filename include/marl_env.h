@@ -273,13 +273,20 @@ typedef struct MarlPolicyIO {
 
 /* PPOAgent.get_action for E envs x M agents (agents/ppo_agent.py:193-225): Actor.sample (agents/actor.py:118-202)
  * and Critic.forward_pooled (agents/critic.py:124-134) in one launch, float32.  hidden = 64 or 128.
- * Packed weights (floats, torch layouts: Linear.weight is [out][in]):
- *   actor : trunk.0.weight [H][5], trunk.0.bias [H], trunk.1.weight [H], trunk.1.bias [H] (LayerNorm),
- *           trunk.3.weight as [H/4][H][4] with entry (t, k) = (W[4t][k], W[4t+1][k], W[4t+2][k], W[4t+3][k]), trunk.3.bias [H],
- *           trunk.4.weight [H], trunk.4.bias [H], heads as [H][8] with row j = column j of
- *           (mu_head, log_std_head, band_head) stacked, head biases [8]
- *   critic: network.0.weight [H][5], network.0.bias [H], network.2.weight as [H/4][H][4] (as above),
- *           network.2.bias [H], network.4.weight [H], network.4.bias [1] */
+ * Packed weights (floats; torch layouts: Linear.weight is [out][in]).  Matrices are stored as the A-operand
+ * fragments of v_mfma_f32_32x32x2 (output units on the rows of the product, 32 agents on its columns), so that the
+ * accumulators of one layer are the B operand of the next without a shuffle.  With
+ *     unit(s, h) = 32 (s / 16) + 8 ((s % 16) / 4) + 4 h + s % 4        (s = 0 .. H/2 - 1, h = 0, 1)
+ * the hidden unit that a lane of wave half h holds in its s-th accumulator register, and lane l = 0 .. 63:
+ *   first(W, b)  [H/32][3][64]      entry (bo, s, l) = [W | b][32 bo + l % 32][2 s + l / 32]   (bias = input 5)
+ *   hidden(W)    [H/32][H/8][64][4] entry (bo, g, l, q) = W[32 bo + l % 32][unit(4 g + q, l / 32)]
+ *   heads(W)     [H/8][64][4]       as hidden() with one block: rows 0..7 = (mu_head, log_std_head, band_head)
+ *                                   stacked, rows 8..31 zero
+ *   actor : first(trunk.0), trunk.1.weight [H], trunk.1.bias [H] (LayerNorm), hidden(trunk.3.weight), trunk.3.bias [H],
+ *           trunk.4.weight [H], trunk.4.bias [H], heads(...), head biases [8]
+ *   critic: first(network.0), hidden(network.2.weight), network.2.bias [H], network.4.weight [H],
+ *           network.4.bias [1] + 3 floats of padding
+ * marl_amd.agents.pack_policy_weights builds this buffer from the torch modules. */
 size_t marl_policy_weight_count(int32_t hidden);
 int marl_policy_act(int32_t E, int32_t M, int32_t hidden, float v_max, float log_std_min, float log_std_max,
                     const MarlPolicyIO *io, void *stream);
