@@ -2529,45 +2529,54 @@ __global__ __launch_bounds__(WAVE) void pair_bits_big_kernel(MarlEnvParams P, co
 template <int CH, int B>
 struct TeamCols {
     static constexpr int C0 = B * 4;
-    static __device__ __forceinline__ void matvec(const double (&a)[CH], const double* u16, int lh, double& p0,
-                                                  double& p1, double cur, double nxt) {
+    // LDS holds the pivot column v; u differs from it in entry l only (u_l = v_l - g).  The lane whose chunk entry
+    // is that one (fq == first column of the chunk) swaps it in after the read.
+    static __device__ __forceinline__ double fixed(double chunk, int fq, double ul) { return (fq == C0) ? ul : chunk; }
+    static __device__ __forceinline__ void matvec(const double (&a)[CH], const double* u16, int lh, int fq, double ul,
+                                                  double& p0, double& p1, double cur, double nxt) {
         if constexpr (C0 < CH) {
             if constexpr (B > 0) {
                 if (C0 > lh) return;
             }
             if constexpr (C0 % 16 == 0) {
-                if constexpr (B > 0) cur = nxt;
+                cur = fixed(B > 0 ? nxt : cur, fq, ul);
                 if constexpr (C0 + 16 < CH) nxt = u16[C0 + 16];
             }
             static_for<0, 4>([&](auto jj) {
                 constexpr int c = C0 + decltype(jj)::value;
                 if constexpr (c < CH) fmac_row_bcast<c % 16, (c % 16 < 2)>((c & 1) ? p1 : p0, cur, a[c]);
             });
-            TeamCols<CH, B + 1>::matvec(a, u16, lh, p0, p1, cur, nxt);
+            TeamCols<CH, B + 1>::matvec(a, u16, lh, fq, ul, p0, p1, cur, nxt);
         }
     }
-    // a[c] += nu * p_c + nw * u_c  (nu = -u_row, nw = -w_row)
-    static __device__ __forceinline__ void update(double (&a)[CH], const double& nu, const double& nw, int lh,
-                                                  const double* u16, const double* p16, double cu, double nu16,
-                                                  double cp, double np16) {
-        if constexpr (C0 < CH) {
-            if constexpr (B > 0) {
-                if (C0 > lh) return;
-            }
-            if constexpr (C0 % 16 == 0) {
-                if constexpr (B > 0) { cu = nu16; cp = np16; }
-                if constexpr (C0 + 16 < CH) { nu16 = u16[C0 + 16]; np16 = p16[C0 + 16]; }
-            }
-            static_for<0, 4>([&](auto jj) {
-                constexpr int c = C0 + decltype(jj)::value;
-                if constexpr (c < CH) fmac_row_bcast<c % 16, (c % 16 < 2)>(a[c], cp, nu);
-            });
-            static_for<0, 4>([&](auto jj) {
-                constexpr int c = C0 + decltype(jj)::value;
-                if constexpr (c < CH) fmac_row_bcast<c % 16, false>(a[c], cu, nw);
-            });
-            TeamCols<CH, B + 1>::update(a, nu, nw, lh, u16, p16, cu, nu16, cp, np16);
+    // a[c] += nu * p_c + nw * u_c  (nu = -u_row, nw = -w_row); returns a[lh] (the thread's part of the next
+    // pivot column) from the last block it visits.
+    static __device__ __forceinline__ double update(double (&a)[CH], const double& nu, const double& nw, int lh, int fq,
+                                                    double ul, const double* u16, const double* p16, double cu,
+                                                    double nu16, double cp, double np16) {
+        if constexpr (C0 % 16 == 0) {
+            cu = fixed(B > 0 ? nu16 : cu, fq, ul);
+            if constexpr (B > 0) cp = np16;
+            if constexpr (C0 + 16 < CH) { nu16 = u16[C0 + 16]; np16 = p16[C0 + 16]; }
         }
+        static_for<0, 4>([&](auto jj) {
+            constexpr int c = C0 + decltype(jj)::value;
+            if constexpr (c < CH) fmac_row_bcast<c % 16, (c % 16 < 2)>(a[c], cp, nu);
+        });
+        static_for<0, 4>([&](auto jj) {
+            constexpr int c = C0 + decltype(jj)::value;
+            if constexpr (c < CH) fmac_row_bcast<c % 16, false>(a[c], cu, nw);
+        });
+        if constexpr (C0 + 4 < CH) {
+            if (lh >= C0 + 4) return TeamCols<CH, B + 1>::update(a, nu, nw, lh, fq, ul, u16, p16, cu, nu16, cp, np16);
+        }
+        const int w = lh - C0;                                   // wave-uniform
+        double v = a[C0];
+        static_for<1, 4>([&](auto jj) {
+            constexpr int c = C0 + decltype(jj)::value;
+            if constexpr (c < CH) v = (w == decltype(jj)::value) ? a[c] : v;
+        });
+        return v;
     }
 };
 // The value of the lane 16 away inside the same half wave (ds_swizzle, bit mode: lane ^ 16).
@@ -2583,11 +2592,12 @@ constexpr int TEAM_ROWS = TEAM_THREADS / 2;
 
 template <int CH>
 struct TeamLds {
-    double colbuf[TEAM_ROWS];                                     // pivot column, one entry per row
-    __attribute__((aligned(16))) double uh[2][TEAM_ROWS / 2 + 8];  // u by column parity
-    __attribute__((aligned(16))) double qh[2][TEAM_ROWS / 2 + 8];  // p = A u / h by column parity
-    double2 de[TEAM_ROWS];                                        // tridiagonal: (diagonal, squared off-diagonal)
+    __attribute__((aligned(16))) double vh[2][2][TEAM_ROWS / 2 + 8];   // pivot column by step parity and column parity
+    __attribute__((aligned(16))) double qh[2][TEAM_ROWS / 2 + 8];      // p = A u / h by column parity
+    double2 de[TEAM_ROWS];                                             // tridiagonal: (diagonal, squared off-diagonal)
     double red[2][TEAM_WAVES];
+    double aii;
+    double tail[3];
     int redi[TEAM_WAVES];
 };
 
@@ -2620,44 +2630,50 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
         a[k] = (r < np) ? ((c == r) ? (double)cdeg : off) : 0.0;
     });
 
-    // Three workgroup barriers per step.  The rank-2 update is applied in the form
-    //   A -= u p^T + w u^T,  w = p - 2K u   (= u q^T + q u^T with q = p - K u),
-    // so that p can be published together with the partial sums of K instead of after them.
+    // Two workgroup barriers per step.  Barrier 1 publishes the pivot column v and the partial sums of |v|^2:
+    // u = v except u_l = v_l - g, which every thread works out for itself and swaps into the chunks it reads
+    // (TeamCols::fixed).  Barrier 2 publishes p = A u / H with the partial sums of K; the rank-2 update is
+    // applied in the form  A -= u p^T + w u^T,  w = p - 2K u  (= u q^T + q u^T with q = p - K u), so that p
+    // need not wait for K.  The update hands back the thread's part of the next pivot column.  v is double
+    // buffered: a fast wave writes the next column while a slow one still reads this one.
 #ifdef MARL_EXP_TIMING
     double tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tlast;
     asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
 #endif
+    double mine = column_of<CH, 0, CH>(a, (np - 1) >> 1);
     for (int i = np - 1; i >= 2; --i) {
-        const int l = i - 1, lh = l >> 1;
-        double mine = column_of<CH, 0, CH>(a, i >> 1);
+        const int l = i - 1, lh = l >> 1, buf = i & 1;
         TSTAMP(0, mine);
         const double other = swap16(mine);                          // the partner's value
         const double v = (h == (i & 1)) ? mine : other;             // A[r][i]
-        double uj = (r <= l) ? v : 0.0;
-        const double hw = wave_sum_dpp(h == 0 ? uj * uj : 0.0);
-        if (h == 0) L.colbuf[r] = v;
+        const double vj = (r <= l) ? v : 0.0;
+        const double hw = wave_sum_dpp(h == 0 ? vj * vj : 0.0);
+        if (h == 0) {
+            L.vh[buf][r & 1][r >> 1] = vj;
+            if (r == i) L.aii = v;
+        }
         if (lane == 0) L.red[0][wave] = hw;
-        TSTAMP(1, uj);
+        TSTAMP(1, mine);
         __syncthreads();
-        TSTAMP(2, uj);
-        const double aii = L.colbuf[i], f = L.colbuf[l];
+        TSTAMP(2, mine);
+        const double f = L.vh[buf][l & 1][lh];
         double hsum = 0.0;
 #pragma unroll
         for (int k = 0; k < TEAM_WAVES; ++k) hsum += L.red[0][k];
-        if (tid == 0) L.de[i] = make_double2(aii, hsum);
+        if (tid == 0) L.de[i] = make_double2(L.aii, hsum);
         const double sq = (hsum > 0.0) ? fast_sqrt(hsum) : 0.0;
         const double g = (f >= 0.0) ? -sq : sq;
         const double h2 = hsum - f * g;
         const double hinv = (hsum > 0.0) ? fast_rcp(h2) : 0.0;
-        if (r == l) uj = f - g;
-        if (h == 0) L.uh[r & 1][r >> 1] = uj;
-        TSTAMP(3, uj);
-        __syncthreads();
+        const double ul = f - g;
+        const double uj = (r == l) ? ul : vj;
+        const int fq = (h == (l & 1)) ? lh - (lane & 15) : -1;      // == 16 q in the lane that holds u_l in chunk q
         double p0 = 0.0, p1 = 0.0;
-        const double* u16 = L.uh[h] + (lane & 15);
+        const double* u16 = L.vh[buf][h] + (lane & 15);
         const double u0 = u16[0];
-        TeamCols<CH, 0>::matvec(a, u16, lh, p0, p1, u0, u0);
+        TSTAMP(3, p0);
+        TeamCols<CH, 0>::matvec(a, u16, lh, fq, ul, p0, p1, u0, u0);
         TSTAMP(4, p0);
         const double ps = p0 + p1;
         const double pr = ps + swap16(ps);
@@ -2666,7 +2682,7 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
         if (h == 0) L.qh[r & 1][r >> 1] = p;
         if (lane == 0) L.red[1][wave] = kw;
         __syncthreads();
-        TSTAMP(5, uj);
+        TSTAMP(5, mine);
         double ksum = 0.0;
 #pragma unroll
         for (int k = 0; k < TEAM_WAVES; ++k) ksum += L.red[1][k];
@@ -2675,9 +2691,9 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
             const double* p16 = L.qh[h] + (lane & 15);
             const double pq0 = p16[0];
             const double nuj = -uj, nwj = -wj;
-            TeamCols<CH, 0>::update(a, nuj, nwj, lh, u16, p16, u0, u0, pq0, pq0);
+            mine = TeamCols<CH, 0>::update(a, nuj, nwj, lh, fq, ul, u16, p16, u0, u0, pq0, pq0);
         }
-        TSTAMP(6, a[0]);
+        TSTAMP(6, mine);
     }
 #ifdef MARL_EXP_TIMING
     {
@@ -2687,13 +2703,13 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
     }
 #endif
     // the remaining 2 x 2 block: A[1][1] is column 1 (parity 1, k = 0) of row 1, A[1][0] and A[0][0] are a[0]
-    if (r == 1 && h == 1) L.colbuf[2] = a[0];
-    if (r == 1 && h == 0) L.colbuf[1] = a[0];
-    if (r == 0 && h == 0) L.colbuf[0] = a[0];
+    if (r == 1 && h == 1) L.tail[2] = a[0];
+    if (r == 1 && h == 0) L.tail[1] = a[0];
+    if (r == 0 && h == 0) L.tail[0] = a[0];
     __syncthreads();
     if (tid == 0) {
-        L.de[1] = make_double2(L.colbuf[2], L.colbuf[1] * L.colbuf[1]);
-        L.de[0] = make_double2(L.colbuf[0], 0.0);
+        L.de[1] = make_double2(L.tail[2], L.tail[1] * L.tail[1]);
+        L.de[0] = make_double2(L.tail[0], 0.0);
     }
     __syncthreads();
     const double lo = (double)(dmax + 1) * (1.0 - 1e-13) - 1e-13;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-section cycles of the team solver's Householder step (library built with -DMARL_EXP_TIMING):
-lambda2 = N - cycles of section (env % 8).  0 pivot column tree, 1 swap + norm partial, 2 barrier 1,
-3 sqrt / rcp / publish u, 4 barrier 2 + matvec, 5 p, K partial, barrier 3, 6 update."""
+lambda2 = N - cycles of section (env % 8).  0 loop top, 1 swap + norm partial + publish v, 2 barrier 1,
+3 sqrt / rcp, 4 matvec, 5 p, K partial, barrier 2, 6 update."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,8 +9,8 @@ from marl_amd import _lib
 from oracle import jammer_oracle as orc
 lib = _lib.load()
 N, E = 200, 2048
-names = ["column tree", "swap + norm partial", "barrier 1", "sqrt/rcp/publish u", "barrier 2 + matvec",
-         "p, K partial, barrier 3", "update", "-"]
+names = ["loop top", "swap + norm partial", "barrier 1", "sqrt/rcp", "matvec",
+         "p, K partial, barrier 2", "update", "-"]
 for k in (100, 200):
     rng = np.random.RandomState(0)
     A = ~np.eye(N, dtype=bool)
