@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--shards", type=int, default=None,
+                    help="parts of the batch stepped on HIP streams of their own (default: 3 for config 3, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
@@ -251,8 +253,9 @@ def main():
                                  "(GAE kernel, 10 epochs x 32 minibatches unless the KL test stops earlier)"}
         env_for_stage = solo
     else:
+        shards = args.shards if args.shards is not None else {3: 3, 2: 2}.get(args.config, 1)
         env = BatchedJammerEnv(E, cfg, seed=1234, device=dev, auto_reset=True, env_offset=rank * E,
-                               write_obs=not cfgd["reward_only"])
+                               write_obs=not cfgd["reward_only"], num_shards=shards)
         env.reset()
         # action pool: v ~ U[-5,5]^2, band ~ U{0..3}; generated on the device before the timed region
         pool_n = 64 if E * M_JAM <= 8192 * 16 else 16
@@ -269,14 +272,32 @@ def main():
         barrier()
         t0 = time.perf_counter()
         e0.record()            # torch records on the current stream, the one env.step launches on
+        env.fork()             # (parts on streams of their own start after e0 ...
         for i in range(steps):
             env.step(pool[(preroll + warmup + i) % pool_n])
+        env.join()             #  ... and e1 waits for them)
         e1.record()
         barrier()
         elapsed = time.perf_counter() - t0
         kern_ms = e0.elapsed_time(e1) / steps
-        extra = {"auto_resets_in_timed_region": (to_end <= steps) + max(0, steps - to_end) // cfg.max_steps,
+        extra = {"streams": shards,
+                 "auto_resets_in_timed_region": (to_end <= steps) + max(0, steps - to_end) // cfg.max_steps,
                  "untimed_preroll_steps": preroll}
+        if shards > 1 and rank == 0:
+            # the same steps as one launch sequence on one stream (what the per-kernel profiles under profiles/ time)
+            one = BatchedJammerEnv(E, cfg, seed=1234, device=dev, auto_reset=True, env_offset=rank * E,
+                                   write_obs=not cfgd["reward_only"])
+            one.reset()
+            for i in range(preroll + warmup):
+                one.step(pool[i % pool_n])
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record()
+            for i in range(steps):
+                one.step(pool[(preroll + warmup + i) % pool_n])
+            f1.record()
+            torch.cuda.synchronize()
+            extra["one_stream_ms_per_step"] = f0.elapsed_time(f1) / steps
+            del one
         env_for_stage = env
     if dist is not None:
         t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
@@ -309,6 +330,8 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_VALU_TFLOPS,
                          "traffic": prof.get("hbm_bytes_per_step"),
                          "kernel": f"marl_env_step = {sched} (+ the masked reset launch on the steps that need it); "
+                                   + (f"the batch in {extra['streams']} parts on streams of their own, whose kernels overlap; "
+                                      if extra.get("streams", 1) > 1 else "") +
                                    "kernel_ms = HIP-event span of the timed loop on the launch stream / steps"
                                    + (" (config 5: of a 50-step loop of the env step alone on the same batch)"
                                       if args.config == 5 else ""),

@@ -183,6 +183,18 @@ int marl_params_init(MarlEnvParams *p);
 size_t marl_state_bytes(const MarlEnvParams *p, int32_t E);
 int marl_state_bind(MarlEnvState *s, const MarlEnvParams *p, int32_t E, void *base);
 
+/* Envs [first, first + count) of a bound state as a state of their own (*out: the same arrays, every per-env
+ * pointer moved to row `first`, E = count), so that parts of one batch can be stepped by separate launches on
+ * separate HIP streams: the front kernel of one part then runs beside the eigen-solves of another.  The envs of
+ * the reference are independent (JammerEnv.step touches self only, environment/jammer_env.py:380-545), so the
+ * results do not depend on the split; pass env_offset + first in the IO structs to keep the generator streams.
+ * `scratch`: marl_shard_scratch_bytes() of device memory private to the part (the launch-ordering histogram),
+ * zeroed once by the caller.  N <= 64 only (larger swarms keep per-batch tables in the workspace):
+ * MARL_EUNSUPPORTED otherwise. */
+size_t marl_shard_scratch_bytes(void);
+int marl_state_shard(const MarlEnvParams *p, const MarlEnvState *whole, int32_t first, int32_t count,
+                     void *scratch, MarlEnvState *out);
+
 const char *marl_strerror(int code);
 int marl_last_hip_error(void);
 
@@ -196,6 +208,17 @@ int marl_env_step(const MarlEnvParams *p, const MarlEnvState *s, const MarlStepI
 
 /* JammerEnv.reset for the masked envs (environment/jammer_env.py:261-354). */
 int marl_env_reset(const MarlEnvParams *p, const MarlEnvState *s, const MarlResetIO *io, void *stream);
+
+/* The same step / reset issued as `parts` launches over consecutive runs of envs (part k: E / parts envs, the first
+ * E % parts parts one more), part k on streams[k]: marl_state_shard and the row offsets of the IO arrays done
+ * here, one call for the host.  `scratch`: parts * marl_shard_scratch_bytes() of zeroed device memory that stays
+ * with this state.  The call orders nothing between the streams and the caller's other work; the caller does.
+ * 1 <= parts <= MARL_MAX_PARTS, N <= 64. */
+#define MARL_MAX_PARTS 16
+int marl_env_step_parts(const MarlEnvParams *p, const MarlEnvState *s, const MarlStepIO *io, int32_t parts,
+                        void *const *streams, void *scratch);
+int marl_env_reset_parts(const MarlEnvParams *p, const MarlEnvState *s, const MarlResetIO *io, int32_t parts,
+                         void *const *streams, void *scratch);
 
 /* ---- separately testable stages -------------------------------------------- */
 

@@ -84,6 +84,13 @@ SYMBOLS = {
     "marl_params_init": (C.c_int, [C.POINTER(MarlEnvParams)]),
     "marl_state_bytes": (C.c_size_t, [C.POINTER(MarlEnvParams), C.c_int32]),
     "marl_state_bind": (C.c_int, [C.POINTER(MarlEnvState), C.POINTER(MarlEnvParams), C.c_int32, C.c_void_p]),
+    "marl_env_step_parts": (C.c_int, [C.POINTER(MarlEnvParams), C.POINTER(MarlEnvState), C.POINTER(MarlStepIO), C.c_int32,
+                                      C.POINTER(C.c_void_p), C.c_void_p]),
+    "marl_env_reset_parts": (C.c_int, [C.POINTER(MarlEnvParams), C.POINTER(MarlEnvState), C.POINTER(MarlResetIO), C.c_int32,
+                                       C.POINTER(C.c_void_p), C.c_void_p]),
+    "marl_shard_scratch_bytes": (C.c_size_t, []),
+    "marl_state_shard": (C.c_int, [C.POINTER(MarlEnvParams), C.POINTER(MarlEnvState), C.c_int32, C.c_int32, C.c_void_p,
+                                   C.POINTER(MarlEnvState)]),
     "marl_strerror": (C.c_char_p, [C.c_int]),
     "marl_last_hip_error": (C.c_int, []),
     "marl_env_step": (C.c_int, [C.POINTER(MarlEnvParams), C.POINTER(MarlEnvState), C.POINTER(MarlStepIO),

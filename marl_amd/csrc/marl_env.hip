@@ -3046,6 +3046,31 @@ int marl_state_bind(MarlEnvState* s, const MarlEnvParams* p, int32_t E, void* ba
     return MARL_OK;
 }
 
+size_t marl_shard_scratch_bytes(void) { return align256(SOLVE_HIST_WORDS * 4); }
+
+int marl_state_shard(const MarlEnvParams* p, const MarlEnvState* whole, int32_t first, int32_t count, void* scratch,
+                     MarlEnvState* out) {
+    if (p == nullptr || whole == nullptr || out == nullptr || scratch == nullptr) return MARL_EINVAL;
+    int rc = check_sizes(p);
+    if (rc != MARL_OK) return rc;
+    if (p->N > WAVE) return MARL_EUNSUPPORTED;
+    if (first < 0 || count < 1 || (long long)first + count > whole->E || ((uintptr_t)scratch & 255) != 0) return MARL_EINVAL;
+    const size_t n = p->N, m = p->M, ks = n + 1, f = (size_t)first;
+    *out = *whole;
+    out->E = count;
+    auto move = [&](auto*& ptr, size_t row) { if (ptr != nullptr) ptr += f * row; };
+    move(out->enemy_x, n); move(out->enemy_y, n); move(out->enemy_vx, n); move(out->enemy_vy, n); move(out->enemy_omega, n);
+    move(out->jam_x, m); move(out->jam_y, m); move(out->jam_band, m); move(out->last_vx, m); move(out->last_vy, m);
+    move(out->step_count, 1); move(out->enemy_band, 1); move(out->tick, 1); move(out->lambda2_initial, 1);
+    move(out->labels, n); move(out->cent_x, ks); move(out->cent_y, ks); move(out->cent_size, ks);
+    move(out->n_clusters, 1); move(out->ncent, 1); move(out->prev_x, ks); move(out->prev_y, ks);
+    move(out->prev_n_clusters, 1); move(out->prev_ncent, 1); move(out->assign, m);
+    move(out->solve_rows, WAVE); move(out->solve_np, 1); move(out->solve_slot, 1); move(out->solve_perm, 1);
+    move(out->solve_partial, 4); move(out->episode_return, 1);
+    out->solve_hist = (int32_t*)scratch;
+    return MARL_OK;
+}
+
 int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepIO* io, void* stream) {
     if (p == nullptr || s == nullptr || io == nullptr) return MARL_EINVAL;
     int rc = check_sizes(p);
@@ -3089,6 +3114,65 @@ int marl_env_reset(const MarlEnvParams* p, const MarlEnvState* s, const MarlRese
     MARL_DISPATCH_NPAD(p->N, env_reset_wave_kernel, dim3(s->E), wave_lds_bytes(p->N), stream, *p, *s, *io);
     return hip_check(hipGetLastError());
 }
+
+static int part_bounds(const MarlEnvParams* p, const MarlEnvState* s, int32_t parts, void* const* streams, void* scratch) {
+    if (p == nullptr || s == nullptr || streams == nullptr || scratch == nullptr) return MARL_EINVAL;
+    if (parts < 1 || parts > MARL_MAX_PARTS || parts > s->E) return MARL_EINVAL;
+    return MARL_OK;
+}
+#define rows_from(base, first, row) ((base) == nullptr ? nullptr : (base) + (first) * (row))
+
+int marl_env_step_parts(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepIO* io, int32_t parts,
+                        void* const* streams, void* scratch) {
+    int rc = part_bounds(p, s, parts, streams, scratch);
+    if (rc != MARL_OK || io == nullptr) return rc != MARL_OK ? rc : MARL_EINVAL;
+    const size_t n = p->N, m = p->M, w = (n + 31) / 32;
+    int32_t first = 0;
+    for (int32_t k = 0; k < parts; ++k) {
+        const int32_t count = s->E / parts + (k < s->E % parts ? 1 : 0);
+        MarlEnvState part;
+        rc = marl_state_shard(p, s, first, count, (unsigned char*)scratch + (size_t)k * marl_shard_scratch_bytes(), &part);
+        if (rc != MARL_OK) return rc;
+        MarlStepIO o = *io;
+        const size_t f = (size_t)first;
+        o.actions = rows_from(io->actions, f, m * 3); o.noise = rows_from(io->noise, f, n * 2);
+        o.obs = rows_from(io->obs, f, m * MARL_OBS_DIM); o.reward = rows_from(io->reward, f, 1);
+        o.truncated = rows_from(io->truncated, f, 1); o.lambda2 = rows_from(io->lambda2, f, 1);
+        o.reward_terms = rows_from(io->reward_terms, f, 5); o.avg_power_dbm = rows_from(io->avg_power_dbm, f, 1);
+        o.adj_bits = rows_from(io->adj_bits, f, n * w); o.jam_bits = rows_from(io->jam_bits, f, n * w);
+        o.env_offset = io->env_offset + f;
+        rc = marl_env_step(p, &part, &o, streams[k]);
+        if (rc != MARL_OK) return rc;
+        first += count;
+    }
+    return MARL_OK;
+}
+
+int marl_env_reset_parts(const MarlEnvParams* p, const MarlEnvState* s, const MarlResetIO* io, int32_t parts,
+                         void* const* streams, void* scratch) {
+    int rc = part_bounds(p, s, parts, streams, scratch);
+    if (rc != MARL_OK || io == nullptr) return rc != MARL_OK ? rc : MARL_EINVAL;
+    const size_t n = p->N, m = p->M;
+    int32_t first = 0;
+    for (int32_t k = 0; k < parts; ++k) {
+        const int32_t count = s->E / parts + (k < s->E % parts ? 1 : 0);
+        MarlEnvState part;
+        rc = marl_state_shard(p, s, first, count, (unsigned char*)scratch + (size_t)k * marl_shard_scratch_bytes(), &part);
+        if (rc != MARL_OK) return rc;
+        MarlResetIO o = *io;
+        const size_t f = (size_t)first;
+        o.mask = rows_from(io->mask, f, 1); o.enemy_pos = rows_from(io->enemy_pos, f, n * 2);
+        o.enemy_vel = rows_from(io->enemy_vel, f, n * 2); o.enemy_omega = rows_from(io->enemy_omega, f, n);
+        o.enemy_band = rows_from(io->enemy_band, f, 1); o.jam_init = rows_from(io->jam_init, f, m * 2);
+        o.jam_band = rows_from(io->jam_band, f, m); o.obs = rows_from(io->obs, f, m * MARL_OBS_DIM);
+        o.env_offset = io->env_offset + f;
+        rc = marl_env_reset(p, &part, &o, streams[k]);
+        if (rc != MARL_OK) return rc;
+        first += count;
+    }
+    return MARL_OK;
+}
+#undef rows_from
 
 int marl_adjacency_bits(const MarlEnvParams* p, int32_t E, const double* x, const double* y, const int32_t* band,
                         uint32_t* bits, void* stream) {

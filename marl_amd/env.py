@@ -127,13 +127,19 @@ class BatchedJammerEnv:
     observation of the next episode, as the reference trainer does
     (training/trainer.py:248-278); the terminal-step metrics stay in `info`
     (`lambda2_current`, `episode_lambda2_initial`).
+
+    `num_shards=S` (N <= 64) steps the batch as S parts on S HIP streams of their own, so that the front
+    kernel of one part runs beside the eigen-solves of another; the envs are independent
+    (environment/jammer_env.py:380-545), so the results are those of one launch.  step() then does not wait:
+    call fork() after producing actions on the current stream (the parts' streams wait for it) and join()
+    before reading results on the current stream; step after step may be issued without either.
     """
 
     AUTO_RESET_EPISODE = 0x5EED5EED
 
     def __init__(self, num_envs: int, config: Optional[EnvConfig] = None, seed: int = 0, device="cuda",
                  auto_reset: bool = True, env_offset: int = 0, track_avg_power: bool = False,
-                 debug_bits: bool = False, write_obs: bool = True, **cfg_kwargs):
+                 debug_bits: bool = False, write_obs: bool = True, num_shards: int = 1, **cfg_kwargs):
         self.cfg = config if config is not None else EnvConfig(**cfg_kwargs)
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -173,6 +179,26 @@ class BatchedJammerEnv:
             self.adj_bits = torch.zeros(self.E, self.N, W, dtype=torch.int32, device=self.device) if debug_bits else None
             self.jam_bits = torch.zeros(self.E, self.N, W, dtype=torch.int32, device=self.device) if debug_bits else None
             self._terminated = torch.zeros(self.E, dtype=torch.bool, device=self.device)
+            self._shards = []            # (first, count, MarlEnvState, stream) per part when num_shards > 1
+            S = int(num_shards)
+            if S < 1 or S > self.E:
+                raise ValueError("num_shards must be in 1..num_envs")
+            if S > 1:
+                sb = self.lib.marl_shard_scratch_bytes()
+                self._shard_scratch = torch.zeros(S * sb + 256, dtype=torch.uint8, device=self.device)
+                sbase = (self._shard_scratch.data_ptr() + 255) & ~255
+                self._ep_l0 = torch.zeros(self.E, dtype=torch.float64, device=self.device)
+                self._ep_step = torch.zeros(self.E, dtype=torch.int32, device=self.device)
+                first = 0
+                for k in range(S):
+                    count = self.E // S + (1 if k < self.E % S else 0)
+                    st = MarlEnvState()
+                    _lib.check(self.lib.marl_state_shard(C.byref(self.params), C.byref(self.state), first, count,
+                                                         C.c_void_p(sbase + k * sb), C.byref(st)), "marl_state_shard")
+                    self._shards.append((first, count, st, torch.cuda.Stream(device=self.device)))
+                    first += count
+                self._part_streams = (C.c_void_p * S)(*[sh[3].cuda_stream for sh in self._shards])
+                self._part_scratch = C.c_void_p(sbase)
         self._episode = 0
         # Host-side bounds on the envs' step counters (min, max); None = unknown.  While the largest
         # counter cannot have reached max_steps no env is truncated and the masked auto-reset launch is
@@ -181,6 +207,19 @@ class BatchedJammerEnv:
         # turns the bookkeeping off for good.
         self._count_bounds: Optional[list] = None
         self._track_counts = True
+
+    # -- parts on their own streams -------------------------------------------
+    def fork(self):
+        """The parts' streams wait for the work queued on the current stream so far."""
+        cur = torch.cuda.current_stream(self.device)
+        for _, _, _, stream in self._shards:
+            stream.wait_stream(cur)
+
+    def join(self):
+        """The current stream waits for the steps queued on the parts' streams so far."""
+        cur = torch.cuda.current_stream(self.device)
+        for _, _, _, stream in self._shards:
+            cur.wait_stream(stream)
 
     # -- reset ---------------------------------------------------------------
     def reset(self, seed: Optional[int] = None, mask: Optional[torch.Tensor] = None, *,
@@ -195,6 +234,7 @@ class BatchedJammerEnv:
             self._episode = 0
         io = MarlResetIO()
         keep = []
+        self.join()                     # a reset runs on the current stream, after every step queued so far
 
         def dev(t, dtype):
             if t is None:
@@ -219,6 +259,7 @@ class BatchedJammerEnv:
             _lib.check(self.lib.marl_env_reset(C.byref(self.params), C.byref(self.state), C.byref(io), _stream()),
                        "marl_env_reset")
         self._keepalive = keep
+        self.fork()
         if mask is None:
             self._count_bounds = [0, 0]
         elif self._count_bounds is not None:
@@ -251,21 +292,30 @@ class BatchedJammerEnv:
         obs = self.obs if out_obs is None else out_obs
         reward = self.reward if out_reward is None else out_reward
         trunc = self._trunc_u8 if out_truncated is None else out_truncated
+        stats = None
+        if episode_stats is not None:
+            if episode_stats.dtype != torch.float64 or episode_stats.numel() < 4 or episode_stats.device != self.device:
+                raise ValueError("episode_stats must be a float64 device tensor of 4 elements")
+            stats = episode_stats.data_ptr()
+        with_obs = self.write_obs or out_obs is not None
+
         io = MarlStepIO()
         io.actions, io.noise = actions.data_ptr(), _ptr(noise)
-        io.obs = obs.data_ptr() if (self.write_obs or out_obs is not None) else None
+        io.obs = obs.data_ptr() if with_obs else None
         io.reward, io.truncated = reward.data_ptr(), trunc.data_ptr()
         io.lambda2, io.reward_terms = self.lambda2.data_ptr(), self.reward_terms.data_ptr()
         io.avg_power_dbm = _ptr(self.avg_power)
         io.adj_bits, io.jam_bits = _ptr(self.adj_bits), _ptr(self.jam_bits)
-        if episode_stats is not None:
-            if episode_stats.dtype != torch.float64 or episode_stats.numel() < 4 or episode_stats.device != self.device:
-                raise ValueError("episode_stats must be a float64 device tensor of 4 elements")
-            io.episode_stats = episode_stats.data_ptr()
+        io.episode_stats = stats
         io.seed, io.env_offset = self.seed, self.env_offset
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.marl_env_step(C.byref(self.params), C.byref(self.state), C.byref(io), _stream()),
-                       "marl_env_step")
+            if self._shards:
+                _lib.check(self.lib.marl_env_step_parts(C.byref(self.params), C.byref(self.state), C.byref(io),
+                                                        len(self._shards), self._part_streams, self._part_scratch),
+                           "marl_env_step_parts")
+            else:
+                _lib.check(self.lib.marl_env_step(C.byref(self.params), C.byref(self.state), C.byref(io), _stream()),
+                           "marl_env_step")
         v = self.views
         info: Dict[str, Any] = dict(lambda2_current=self.lambda2, lambda2_initial=v["lambda2_initial"],
                                     enemy_band=v["enemy_band"], n_clusters=v["n_clusters"],
@@ -284,22 +334,34 @@ class BatchedJammerEnv:
             info["episode_lambda2_initial"] = v["lambda2_initial"]
             info["episode_step"] = v["step_count"]
         elif self.auto_reset:
-            if episode_info:
+            if episode_info and not self._shards:
                 info["episode_lambda2_initial"] = v["lambda2_initial"].clone()
                 info["episode_step"] = v["step_count"].clone()
+            elif episode_info:
+                info["episode_lambda2_initial"], info["episode_step"] = self._ep_l0, self._ep_step
             if b is not None:
                 # envs at max_steps start over; if even the smallest counter is there, all of them do
                 self._count_bounds = [0, 0] if b[0] >= self.cfg.max_steps else [0, self.cfg.max_steps - 1]
-            rio = MarlResetIO()
-            rio.mask = trunc.data_ptr()
-            rio.obs = io.obs
             # The draws of an auto-reset are keyed by the env's step clock (`tick`, never rewound) alone: the
             # episode word stays constant, so that the launch is the same whether it is issued eagerly, left
             # out because nothing could be done, or replayed from a captured graph.
+            rio = MarlResetIO()
+            rio.mask = trunc.data_ptr()
+            rio.obs = io.obs
             rio.seed, rio.episode, rio.env_offset = self.seed, self.AUTO_RESET_EPISODE, self.env_offset
             with torch.cuda.device(self.device):
-                _lib.check(self.lib.marl_env_reset(C.byref(self.params), C.byref(self.state), C.byref(rio),
-                                                   _stream()), "marl_env_reset")
+                if self._shards:
+                    if episode_info:
+                        for first, count, _, stream in self._shards:      # pre-reset copies, on the part's own stream
+                            with torch.cuda.stream(stream):
+                                self._ep_l0[first:first + count].copy_(v["lambda2_initial"][first:first + count])
+                                self._ep_step[first:first + count].copy_(v["step_count"][first:first + count])
+                    _lib.check(self.lib.marl_env_reset_parts(C.byref(self.params), C.byref(self.state), C.byref(rio),
+                                                             len(self._shards), self._part_streams, self._part_scratch),
+                               "marl_env_reset_parts")
+                else:
+                    _lib.check(self.lib.marl_env_reset(C.byref(self.params), C.byref(self.state), C.byref(rio),
+                                                       _stream()), "marl_env_reset")
         return obs, reward, self._terminated, truncated, info
 
     def reward_per_agent(self, lambda2: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import golden_util as gu
-from marl_amd import BatchedJammerEnv, EnvConfig, JammerEnv
+from marl_amd import BatchedJammerEnv, EnvConfig, JammerEnv, _lib
 from oracle import jammer_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -195,6 +195,55 @@ def test_two_shards_equal_one_batch_across_auto_resets(N, M, E):
     def digest(env):
         return sum(int(env.views[n].view(torch.uint8).to(torch.int64).sum()) for n in ("enemy_x", "jam_x", "labels"))
     assert digest(whole) == digest(halves[0]) + digest(halves[1])
+
+
+@pytest.mark.parametrize("N,M,E,S", [(50, 8, 4099, 3), (10, 4, 2048, 2), (33, 5, 1500, 4)])
+def test_parts_on_their_own_streams_equal_one_launch(N, M, E, S):
+    """num_shards=S steps the batch as S parts on S streams (no waiting between steps); after join() every
+    output and the whole state equal those of the single launch, over two auto-resets, with the episode
+    statistics summed over the parts."""
+    T = 7
+    cfg = EnvConfig.fast_preset(N=N, M=M, max_steps=T)
+    one = BatchedJammerEnv(E, cfg, seed=77, auto_reset=True, env_offset=11)
+    parts = BatchedJammerEnv(E, cfg, seed=77, auto_reset=True, env_offset=11, num_shards=S)
+    assert len(parts._shards) == S and sum(c for _, c, _, _ in parts._shards) == E
+    o1, _ = one.reset()
+    o2, _ = parts.reset()
+    assert torch.equal(o1, o2)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    acts = (torch.rand(2 * T + 2, E, M, 3, device="cuda", generator=g) - 0.5) * 11
+    acts[..., 2] = torch.randint(0, 4, (2 * T + 2, E, M), device="cuda", generator=g).float()
+    st1 = torch.zeros(4, dtype=torch.float64, device="cuda")
+    st2 = torch.zeros(4, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    parts.fork()
+    for t in range(acts.shape[0]):
+        o1, r1, _, t1, i1 = one.step(acts[t], episode_stats=st1)
+        o2, r2, _, t2, i2 = parts.step(acts[t], episode_stats=st2)
+        if t % 5 == 4 or t == acts.shape[0] - 1:
+            parts.join()
+            torch.cuda.synchronize()
+            assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(t1, t2), t
+            assert torch.equal(i1["lambda2_current"], i2["lambda2_current"]), t
+            assert torch.equal(i1["reward_terms"], i2["reward_terms"]), t
+            for n, v in one.views.items():
+                if not n.startswith("solve_") and n != "workspace":
+                    assert torch.equal(v, parts.views[n]), (t, n)
+    assert st1[0] == 2 * E and st2[0] == st1[0] and st2[3] == st1[3]
+    assert torch.allclose(st1, st2, rtol=1e-12)
+    # a full reset goes through the current stream and orders itself against the parts
+    assert torch.equal(one.reset(seed=5)[0], parts.reset(seed=5)[0])
+    o1 = one.step(acts[0])[0]
+    o2 = parts.step(acts[0])[0]
+    parts.join()
+    assert torch.equal(o1, o2)
+
+
+def test_parts_need_the_wave_kernels():
+    with pytest.raises(_lib.MarlError):
+        BatchedJammerEnv(64, EnvConfig.fast_preset(N=100, M=4), num_shards=2)
+    with pytest.raises(ValueError):
+        BatchedJammerEnv(4, EnvConfig.fast_preset(N=10, M=4), num_shards=5)
 
 
 # ---------------------------------------------------------------- float32 first stage of the step's jamming test
