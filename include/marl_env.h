@@ -314,6 +314,48 @@ size_t marl_policy_weight_count(int32_t hidden);
 int marl_policy_act(int32_t E, int32_t M, int32_t hidden, float v_max, float log_std_min, float log_std_max,
                     const MarlPolicyIO *io, void *stream);
 
+/* ---- PPO minibatch step: the per-row pass -------------------------------------------------------------
+ * PPOAgent.update (agents/ppo_agent.py:296-331) for one minibatch, up to the sums over rows: forward of actor
+ * (Actor.evaluate_actions, agents/actor.py:204-247) and critic (agents/critic.py:124-134, applied to the row's
+ * observation as the reference's update does), the losses
+ *     actor  = mean(-min(ratio A, clip(ratio, 1 +- eps) A)) - c2 mean(entropy),   critic = c1 mean((V - R)^2),
+ * and the backward pass down to every layer's pre-activation, one minibatch row per lane on the matrix cores.
+ * The gradient of a parameter is then a product of two of the [B][.] matrices written here (the 1/B of the means
+ * is already applied):
+ *   actor   trunk.0 [W | b] = dz1^T xe[:, :6]      trunk.1 (LayerNorm) bias = colsum le1, weight = colsum lg1
+ *           trunk.3 [W | b] = dz2^T y1e[:, :H+1]   trunk.4 bias = colsum le2, weight = colsum lg2
+ *           heads   [W | b] = dh^T y2e[:, :H+1]          (rows: mu 0-1, log_std 2-3, band 4-7)
+ *   critic  network.0 [W | b] = cdz1^T xe[:, :6]   network.2 [W | b] = cdz2^T cy1e[:, :H+1]   network.4 [W | b] = dv^T cy2e[:, :H+1]
+ * `stats` (float64 [5], added to): sums over the rows of the actor loss term, c1 (V - R)^2, the entropy, the
+ * clip indicator |ratio - 1| > eps and the KL estimate (ratio - 1) - log ratio (ppo_agent.py:333-345).
+ * hidden = 64 or 128; weights: marl_ppo_weight_count(hidden) floats, the layout of marl_policy_act's buffer with
+ * the fragments of the transposed matrices added (marl_amd.agents.TrainPacker):
+ *   actor : first(trunk.0), LN1 weight, bias, hidden(trunk.3.weight), trunk.3.bias, LN2 weight, bias, heads(W), head
+ *           biases [8], headsT [H/32][4][64]: entry (b, s, l) = W_heads[2 s + l / 32][32 b + l % 32], hidden(trunk.3.weight^T)
+ *   critic: first(network.0), hidden(network.2.weight), network.2.bias, network.4.weight [H], network.4.bias + 3 pad,
+ *           hidden(network.2.weight^T) */
+typedef struct MarlPpoIO {
+    const float *weights;
+    const float *obs;            /* [R][5]  flattened rollout buffer (rollout_buffer.py:231-269) */
+    const float *actions;        /* [R][3] */
+    const float *old_log_probs;  /* [R] */
+    const float *advantages;     /* [R] */
+    const float *returns;        /* [R] */
+    const int64_t *index;        /* [B] rows of the minibatch; NULL = rows 0 .. B-1 */
+    float *xe;                   /* [B][8]    out: obs, 1, 0, 0 */
+    float *y1e, *y2e;            /* [B][H+4]  out: actor activations after each LayerNorm + ReLU, then 1, 0, 0, 0 */
+    float *dz1, *le1, *lg1;      /* [B][H]    out, actor layer 1: dL/dz, dL/d(LayerNorm output), the same times the normalised z */
+    float *dz2, *le2, *lg2;      /* [B][H]    out, actor layer 2 */
+    float *dh;                   /* [B][8]    out: dL/d(head outputs) */
+    float *cy1e, *cy2e;          /* [B][H+4]  out: critic activations, then 1, 0, 0, 0 */
+    float *cdz1, *cdz2;          /* [B][H]    out: critic dL/dz per layer */
+    float *dv;                   /* [B]       out: dL/dV */
+    double *stats;               /* [5] in/out, optional */
+    float clip_eps, c1, c2, v_max, log_std_min, log_std_max;
+} MarlPpoIO;
+size_t marl_ppo_weight_count(int32_t hidden);
+int marl_ppo_rows(int32_t B, int32_t hidden, const MarlPpoIO *io, void *stream);
+
 /* The enemy-noise draw the step kernel uses when MarlStepIO.noise is NULL,
  * written out as [E][N][2] for step numbers step_count[e] + 1. */
 int marl_fill_noise(const MarlEnvParams *p, const MarlEnvState *s, uint64_t seed,

@@ -248,43 +248,112 @@ def _fragment_order(H: int, device):
     return (32 * b + 8 * (v // 4) + (v % 4))[:, None] + 4 * hl[None, :]          # [H/2, 2]
 
 
+def _frag_first(w, b):
+    """[H, 5], [H] -> [H/32][3][64]: lane l of step s of block bo carries [W | b][32 bo + l % 32][2 s + l // 32]."""
+    dev = w.device
+    NB = w.shape[0] // 32
+    lane = torch.arange(64, device=dev)
+    we = torch.cat([w.detach().float(), b.detach().float()[:, None]], 1)      # [H, 6]
+    rows = (32 * torch.arange(NB, device=dev))[:, None, None] + (lane % 32)[None, None, :]
+    cols = (2 * torch.arange(3, device=dev))[None, :, None] + (lane // 32)[None, None, :]
+    return we[rows, cols].reshape(-1)
+
+
+def _frag_hidden(w):
+    """[32 * blocks, H] (out, in) -> [blocks][H/8][64][4]: lane l of step s of block bo carries
+    W[32 bo + l % 32][unit(s, l // 32)]; four steps side by side."""
+    dev = w.device
+    w = w.detach().float()
+    blocks, H = w.shape[0] // 32, w.shape[1]
+    NS = H // 2
+    lane = torch.arange(64, device=dev)
+    unit = _fragment_order(H, dev)                                                                   # [NS, 2]
+    rows = (32 * torch.arange(blocks, device=dev))[:, None, None] + (lane % 32)[None, None, :]      # [blocks, 1, 64]
+    cols = unit[:, lane // 32][None, :, :]                                                           # [1, NS, 64]
+    f = w[rows, cols]                                                                                # [blocks, NS, 64]
+    return f.reshape(blocks, NS // 4, 4, 64).permute(0, 1, 3, 2).reshape(-1)
+
+
+def _frag_heads_t(wh):
+    """[8, H] -> [H/32][4][64]: lane l of step s of block b carries W_heads[2 s + l // 32][32 b + l % 32]."""
+    dev = wh.device
+    wh = wh.detach().float()
+    NB = wh.shape[1] // 32
+    lane = torch.arange(64, device=dev)
+    rows = (2 * torch.arange(4, device=dev))[None, :, None] + (lane // 32)[None, None, :]
+    cols = (32 * torch.arange(NB, device=dev))[:, None, None] + (lane % 32)[None, None, :]
+    return wh[rows, cols].reshape(-1)
+
+
+def _heads(actor):
+    H = actor.hidden_dim
+    w = torch.cat([actor.mu_head.weight, actor.log_std_head.weight, actor.band_head.weight], 0).detach().float()      # [8, H]
+    w32 = torch.zeros(32, H, device=w.device)
+    w32[:8] = w
+    b = torch.cat([actor.mu_head.bias, actor.log_std_head.bias, actor.band_head.bias], 0).detach().float()
+    return w, w32, b
+
+
+def _check_packable(actor, critic):
+    H = actor.hidden_dim
+    if actor.num_bands != 4 or actor.obs_dim != 5 or critic.hidden_dim != H or H % 32:
+        raise ValueError("the packed kernels take obs_dim 5, 4 bands and equal hidden sizes (multiples of 32) only")
+
+
 def pack_policy_weights(actor: "Actor", critic: "Critic") -> torch.Tensor:
     """Actor and critic parameters as the flat float32 buffer marl_policy_act reads (layout: include/marl_env.h).
     Matrices are stored as the A-operand fragments of v_mfma_f32_32x32x2: for output block bo and step s,
     lane l carries W[32 bo + l % 32][k(s, l // 32)], where k is input 2 s + l // 32 for the first layer (the bias
     as input 5) and the unit the lane's s-th accumulator register holds for the hidden layer and the heads."""
-    H = actor.hidden_dim
-    if actor.num_bands != 4 or actor.obs_dim != 5 or critic.hidden_dim != H or H % 32:
-        raise ValueError("marl_policy_act: obs_dim 5, 4 bands and equal hidden sizes (multiples of 32) only")
-    dev = actor.mu_head.weight.device
-    NB, NS = H // 32, H // 2
-    lane = torch.arange(64, device=dev)
-    row, half = lane % 32, lane // 32
-    unit = _fragment_order(H, dev)                                                # [NS, 2]
-
-    def first(w, b):                   # [H, 5], [H] -> [NB][3][64]
-        we = torch.cat([w.detach().float(), b.detach().float()[:, None]], 1)      # [H, 6]
-        rows = (32 * torch.arange(NB, device=dev))[:, None, None] + row[None, None, :]
-        cols = (2 * torch.arange(3, device=dev))[None, :, None] + half[None, None, :]
-        return we[rows, cols].reshape(-1)
-
-    def hidden(w, blocks):             # [32 * blocks, H] (out, in) -> [blocks][NS/4][64][4]
-        w = w.detach().float()
-        rows = (32 * torch.arange(blocks, device=dev))[:, None, None] + row[None, None, :]        # [blocks, 1, 64]
-        cols = unit[:, half][None, :, :]                                                            # [1, NS, 64]
-        f = w[rows, cols]                                                                           # [blocks, NS, 64]
-        return f.reshape(blocks, NS // 4, 4, 64).permute(0, 1, 3, 2).reshape(-1)
-
+    _check_packable(actor, critic)
     t, n = actor.trunk, critic.network
-    heads_w = torch.zeros(32, H, device=dev)
-    heads_w[:8] = torch.cat([actor.mu_head.weight, actor.log_std_head.weight, actor.band_head.weight], 0).detach()
-    heads_b = torch.cat([actor.mu_head.bias, actor.log_std_head.bias, actor.band_head.bias], 0).detach()
-    parts = [first(t[0].weight, t[0].bias), t[1].weight.detach(), t[1].bias.detach(),
-             hidden(t[3].weight, NB), t[3].bias.detach(), t[4].weight.detach(), t[4].bias.detach(),
-             hidden(heads_w, 1), heads_b,
-             first(n[0].weight, n[0].bias), hidden(n[2].weight, NB), n[2].bias.detach(),
+    _, heads_w32, heads_b = _heads(actor)
+    dev = heads_b.device
+    parts = [_frag_first(t[0].weight, t[0].bias), t[1].weight.detach(), t[1].bias.detach(),
+             _frag_hidden(t[3].weight), t[3].bias.detach(), t[4].weight.detach(), t[4].bias.detach(),
+             _frag_hidden(heads_w32), heads_b,
+             _frag_first(n[0].weight, n[0].bias), _frag_hidden(n[2].weight), n[2].bias.detach(),
              n[4].weight.detach().reshape(-1), n[4].bias.detach(), torch.zeros(3, device=dev)]
     return torch.cat([p.float().reshape(-1) for p in parts]).contiguous()
+
+
+def pack_train_weights(actor: "Actor", critic: "Critic") -> torch.Tensor:
+    """The buffer marl_ppo_rows reads: the policy layout with the fragments of the transposed matrices added
+    (heads^T after the head biases, W2^T at the end of each network; include/marl_env.h)."""
+    _check_packable(actor, critic)
+    t, n = actor.trunk, critic.network
+    heads_w, heads_w32, heads_b = _heads(actor)
+    dev = heads_b.device
+    parts = [_frag_first(t[0].weight, t[0].bias), t[1].weight.detach(), t[1].bias.detach(),
+             _frag_hidden(t[3].weight), t[3].bias.detach(), t[4].weight.detach(), t[4].bias.detach(),
+             _frag_hidden(heads_w32), heads_b, _frag_heads_t(heads_w), _frag_hidden(t[3].weight.detach().t()),
+             _frag_first(n[0].weight, n[0].bias), _frag_hidden(n[2].weight), n[2].bias.detach(),
+             n[4].weight.detach().reshape(-1), n[4].bias.detach(), torch.zeros(3, device=dev),
+             _frag_hidden(n[2].weight.detach().t())]
+    return torch.cat([p.float().reshape(-1) for p in parts]).contiguous()
+
+
+class TrainPacker:
+    """pack_train_weights as ONE gather: the packing is a fixed permutation (with zero padding) of the flat parameter
+    vector, found once by packing stand-in networks whose parameters hold their own flat positions."""
+
+    def __init__(self, actor: "Actor", critic: "Critic"):
+        import copy
+        self.params = list(actor.parameters()) + list(critic.parameters())
+        a2, c2 = copy.deepcopy(actor), copy.deepcopy(critic)
+        pos = 1                                           # position 0 of the flat vector is a constant zero (padding)
+        with torch.no_grad():
+            for q in list(a2.parameters()) + list(c2.parameters()):
+                q.copy_(torch.arange(pos, pos + q.numel(), device=q.device, dtype=torch.float32).view_as(q))
+                pos += q.numel()
+        if pos >= 1 << 24:
+            raise ValueError("too many parameters for float32 positions")
+        self.gather = pack_train_weights(a2, c2).round().long()
+        self.flat = torch.zeros(pos, dtype=torch.float32, device=self.gather.device)
+
+    def pack(self) -> torch.Tensor:
+        torch.cat([p.detach().reshape(-1) for p in self.params], out=self.flat[1:])
+        return self.flat[self.gather]
 
 
 def _dist_on() -> bool:
@@ -352,7 +421,7 @@ class PPOAgent:
     def __init__(self, obs_dim=5, hidden_dim=128, M=4, v_max=5.0, num_bands=4, log_std_min=-1.0, log_std_max=0.5,
                  gamma=0.99, gae_lambda=0.95, clip_eps=0.2, lr_actor=3e-4, lr_critic=1e-3, c1=0.5, c2=0.01,
                  max_grad_norm=0.5, rollout_length=2048, batch_size=256, n_epochs=10, device="auto", num_envs=1,
-                 seed: Optional[int] = None, graph_update: bool = True):
+                 seed: Optional[int] = None, graph_update: bool = True, fused_update: Optional[bool] = None):
         self.obs_dim, self.hidden_dim, self.M, self.v_max, self.num_bands = obs_dim, hidden_dim, M, v_max, num_bands
         self.gamma, self.gae_lambda, self.clip_eps, self.c1, self.c2 = gamma, gae_lambda, clip_eps, c1, c2
         self.c2_initial, self.max_grad_norm = c2, max_grad_norm
@@ -396,6 +465,10 @@ class PPOAgent:
         self.policy_kernel = self.device.type == "cuda" and hidden_dim in (64, 128) and num_bands == 4 and obs_dim == 5
         self._packed, self._packed_stale, self._act_calls = None, True, 0
         self.seed = 0 if seed is None else int(seed)
+        # Minibatch step through libmarl_env.so (marl_ppo_rows: forward, losses and backward of every row in one
+        # launch; the sums over rows as a few GEMMs).  None = wherever the captured graph is not used.
+        self.fused_update = self.policy_kernel and ((not self._graph_update) if fused_update is None else bool(fused_update))
+        self._fz = None
 
     # -- acting (ppo_agent.py:193-225) ----------------------------------------
     @torch.no_grad()
@@ -511,6 +584,75 @@ class PPOAgent:
             return torch.stack([actor_loss, critic_loss, entropy.mean(),
                                 (torch.abs(ratio - 1) > self.clip_eps).float().mean(), kl]).double()
 
+    def _fused_scratch(self, B: int):
+        H = self.hidden_dim
+        if self._fz is None:
+            packer = TrainPacker(self.actor, self.critic)
+            n = _lib.load().marl_ppo_weight_count(H)
+            if n != packer.gather.numel():
+                raise _lib.MarlError(f"packed training weights: {packer.gather.numel()} floats, the library expects {n}")
+            self._fz = {"B": 0, "packer": packer, "stats": torch.zeros(5, dtype=torch.float64, device=self.device)}
+        z = self._fz
+        if z["B"] < B:
+            f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=self.device)
+            z.update(B=B, xe=f(B, 8), y1e=f(B, H + 4), y2e=f(B, H + 4), dz1=f(B, H), le1=f(B, H), lg1=f(B, H),
+                     dz2=f(B, H), le2=f(B, H), lg2=f(B, H), dh=f(B, 8), cy1e=f(B, H + 4), cy2e=f(B, H + 4),
+                     cdz1=f(B, H), cdz2=f(B, H), dv=f(B))
+        return z
+
+    def _fused_forward_backward(self, obs, actions, old_log_probs, advantages, returns, idx) -> torch.Tensor:
+        """_forward_backward for the rows `idx` of the flat rollout tensors, without gathering them: one marl_ppo_rows
+        launch (ppo_agent.py:296-323 per row, on the matrix cores), then every parameter gradient as the product of
+        two of the matrices it wrote.  Leaves the gradients in .grad, returns the five statistics."""
+        B, H = int(idx.numel()), self.hidden_dim
+        z = self._fused_scratch(B)
+        z["stats"].zero_()
+        weights = z["packer"].pack()
+        io = _lib.MarlPpoIO()
+        io.weights = weights.data_ptr()
+        io.obs, io.actions, io.old_log_probs = obs.data_ptr(), actions.data_ptr(), old_log_probs.data_ptr()
+        io.advantages, io.returns, io.index = advantages.data_ptr(), returns.data_ptr(), idx.data_ptr()
+        for k in ("xe", "y1e", "y2e", "dz1", "le1", "lg1", "dz2", "le2", "lg2", "dh", "cy1e", "cy2e", "cdz1", "cdz2", "dv"):
+            setattr(io, k, z[k].data_ptr())
+        io.stats = z["stats"].data_ptr()
+        io.clip_eps, io.c1, io.c2, io.v_max = float(self.clip_eps), float(self.c1), float(self.c2), float(self.v_max)
+        io.log_std_min, io.log_std_max = float(self.actor.log_std_min), float(self.actor.log_std_max)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().marl_ppo_rows(B, H, C.byref(io), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "marl_ppo_rows")
+        s = _split_k(B)
+
+        def rows_product(a, b):            # a [>=B, m], b [>=B, n] -> a[:B]^T b[:B], split over row chunks when tall
+            a, b = a[:B], b[:B]
+            if s > 1:
+                return torch.bmm(a.view(s, B // s, -1).transpose(1, 2), b.view(s, B // s, -1)).sum(0)
+            return a.t() @ b
+
+        def colsum(a):
+            a = a[:B]
+            return a.view(s, B // s, -1).sum(1).sum(0) if s > 1 else a.sum(0)
+
+        t, n = self.actor.trunk, self.critic.network
+        g1 = rows_product(z["dz1"], z["xe"])
+        g2 = rows_product(z["dz2"], z["y1e"])
+        gh = rows_product(z["dh"], z["y2e"])
+        c1 = rows_product(z["cdz1"], z["xe"])
+        c2 = rows_product(z["cdz2"], z["cy1e"])
+        c3 = rows_product(z["dv"].view(-1, 1), z["cy2e"])
+        grads = [(t[0].weight, g1[:, :5]), (t[0].bias, g1[:, 5]), (t[1].weight, colsum(z["lg1"])), (t[1].bias, colsum(z["le1"])),
+                 (t[3].weight, g2[:, :H]), (t[3].bias, g2[:, H]), (t[4].weight, colsum(z["lg2"])), (t[4].bias, colsum(z["le2"])),
+                 (self.actor.mu_head.weight, gh[0:2, :H]), (self.actor.mu_head.bias, gh[0:2, H]),
+                 (self.actor.log_std_head.weight, gh[2:4, :H]), (self.actor.log_std_head.bias, gh[2:4, H]),
+                 (self.actor.band_head.weight, gh[4:8, :H]), (self.actor.band_head.bias, gh[4:8, H]),
+                 (n[0].weight, c1[:, :5]), (n[0].bias, c1[:, 5]), (n[2].weight, c2[:, :H]), (n[2].bias, c2[:, H]),
+                 (n[4].weight, c3[:, :H]), (n[4].bias, c3[:, H])]
+        for p, g in grads:
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            p.grad.copy_(g.reshape(p.shape))
+        self._keep = (weights, idx)                       # the launch reads them after this call returns
+        return z["stats"] / B
+
     def _apply_gradients(self):
         """Gradient-norm clip and both Adam steps (ppo_agent.py:324-325, 330-331)."""
         nn.utils.clip_grad_norm_(self.actor.parameters(), self.max_grad_norm)
@@ -558,6 +700,9 @@ class PPOAgent:
         all-reduce per step and the epoch KL is averaged so that every rank stops together."""
         n = obs.shape[0]
         self._packed_stale = True
+        if self.fused_update:
+            obs, actions, old_log_probs, advantages, returns = (
+                x.to(torch.float32).contiguous() for x in (obs, actions, old_log_probs, advantages, returns))
         keys = ("actor_loss", "critic_loss", "entropy", "clip_fraction", "approx_kl")
         acc = torch.zeros(len(keys), dtype=torch.float64, device=obs.device)
         steps = 0
@@ -570,6 +715,15 @@ class PPOAgent:
             nb = 0
             for s in range(0, n, self.batch_size):
                 idx = perm[s:s + self.batch_size]
+                if self.fused_update:
+                    out = self._fused_forward_backward(obs, actions, old_log_probs, advantages, returns, idx)
+                    self._sync.sync()
+                    self._apply_gradients()
+                    acc += out
+                    epoch_kl += out[4]
+                    nb += 1
+                    steps += 1
+                    continue
                 batch = (obs[idx], actions[idx], old_log_probs[idx], advantages[idx], returns[idx])
                 # the first steps run eagerly (they create the optimiser state), short tail batches too
                 if self._graph_update and self._eager_steps >= 2 and idx.numel() == self.batch_size \

@@ -1,0 +1,463 @@
+// Row pass of the PPO minibatch step (PPOAgent.update, agents/ppo_agent.py:296-331): for every row of a
+// minibatch the forward pass of actor and critic (agents/actor.py:204-247 evaluate_actions,
+// agents/critic.py:124-134), the clipped-surrogate / entropy / value losses, and the backward pass down to
+// the pre-activations of every layer.  What is left of the gradient is a sum over rows per parameter --
+// products of two of the matrices this kernel writes ([B][.] row-major: activations with a column of ones,
+// pre-activation gradients, LayerNorm terms) -- which the caller takes with plain GEMMs.
+//
+// Layout as in the policy kernel (marl_net.h): hidden units on the rows of a matrix-core product, 32 minibatch
+// rows on its columns, a lane owns one minibatch row and half of its hidden units.  The backward products
+// W^T dz use the fragments of the transposed matrices (packed next to the forward ones); the accumulators of
+// one product are the B operand of the next in both directions.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "marl_env.h"
+#include "marl_net.h"
+
+namespace {
+
+using namespace marl_net;
+constexpr int WAVE = 64;
+constexpr int OBS = MARL_OBS_DIM;
+constexpr int PPO_THREADS = 512;
+constexpr int PPO_WAVES = PPO_THREADS / WAVE;
+
+// Offsets (in floats) of the packed training weights, see marl_ppo_weight_count in marl_env.h.
+template <int H>
+struct TrainPack {
+    static constexpr int NB = H / 32, NS = H / 2;
+    static constexpr int a_f1 = 0;                          // [NB][3][64]
+    static constexpr int a_g1 = a_f1 + NB * 3 * 64;
+    static constexpr int a_e1 = a_g1 + H;
+    static constexpr int a_f2 = a_e1 + H;                   // [NB][NS/4][64][4]
+    static constexpr int a_b2 = a_f2 + H * H;
+    static constexpr int a_g2 = a_b2 + H;
+    static constexpr int a_e2 = a_g2 + H;
+    static constexpr int a_fh = a_e2 + H;                   // [NS/4][64][4]
+    static constexpr int a_bh = a_fh + NS * 64;             // [8]
+    static constexpr int a_fhT = a_bh + 8;                  // [NB][4][64]  heads transposed: rows = units, k = head
+    static constexpr int a_f2T = a_fhT + NB * 4 * 64;       // [NB][NS/4][64][4] fragments of W2^T
+    static constexpr int a_end = a_f2T + H * H;
+    static constexpr int c_f1 = a_end;
+    static constexpr int c_f2 = c_f1 + NB * 3 * 64;
+    static constexpr int c_b2 = c_f2 + H * H;
+    static constexpr int c_w3 = c_b2 + H;
+    static constexpr int c_b3 = c_w3 + H;                   // [1] + 3 pad
+    static constexpr int c_f2T = c_b3 + 4;
+    static constexpr int total = c_f2T + H * H;
+    static constexpr int lds_floats = a_end > total - c_f1 ? a_end : total - c_f1;
+};
+
+// z -> (z - mean) * rstd over the H units of the lane's row, in place; returns rstd (eps 1e-5, biased variance).
+template <int NB>
+__device__ __forceinline__ float normalise(floatx16 (&x)[NB]) {
+    constexpr int H = NB * 32;
+    float sum = 0.0f;
+    static_for<0, NB>([&](auto bb) { static_for<0, 16>([&](auto vv) { sum += x[decltype(bb)::value][decltype(vv)::value]; }); });
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / H);
+    float var = 0.0f;
+    static_for<0, NB>([&](auto bb) {
+        static_for<0, 16>([&](auto vv) {
+            const float d = x[decltype(bb)::value][decltype(vv)::value] - mean;
+            var = fmaf(d, d, var);
+        });
+    });
+    var += __shfl_xor(var, 32);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / H) + 1e-5f);
+    static_for<0, NB>([&](auto bb) {
+        static_for<0, 16>([&](auto vv) {
+            x[decltype(bb)::value][decltype(vv)::value] = (x[decltype(bb)::value][decltype(vv)::value] - mean) * rstd;
+        });
+    });
+    return rstd;
+}
+
+// y = relu(n * g + e), written to row `out` (the lane's units, 16 bytes at a time) when `valid`.
+template <int NB>
+__device__ __forceinline__ void affine_relu_store(const floatx16 (&n)[NB], const float* __restrict__ g, const float* __restrict__ e,
+                                                  int hl, floatx16 (&y)[NB], float* __restrict__ out, bool valid) {
+    const float* gb = g + opaque(4 * hl);
+    const float* eb = e + opaque(4 * hl);
+    float* ob = out + 4 * hl;
+    asm volatile("" : "+v"(ob));
+    static_for<0, NB>([&](auto bb) {
+        constexpr int b = decltype(bb)::value;
+        static_for<0, 4>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            constexpr int u = 32 * b + 8 * q;
+            const float4 gq = *reinterpret_cast<const float4*>(gb + u);
+            const float4 eq = *reinterpret_cast<const float4*>(eb + u);
+            float4 r;
+            r.x = fmaxf(fmaf(n[b][4 * q], gq.x, eq.x), 0.0f);
+            r.y = fmaxf(fmaf(n[b][4 * q + 1], gq.y, eq.y), 0.0f);
+            r.z = fmaxf(fmaf(n[b][4 * q + 2], gq.z, eq.z), 0.0f);
+            r.w = fmaxf(fmaf(n[b][4 * q + 3], gq.w, eq.w), 0.0f);
+            y[b][4 * q] = r.x; y[b][4 * q + 1] = r.y; y[b][4 * q + 2] = r.z; y[b][4 * q + 3] = r.w;
+            if (valid) *reinterpret_cast<float4*>(ob + u) = r;
+            LDS_FENCE();
+        });
+    });
+}
+
+// The lane's units of a row, 16 bytes at a time.
+template <int NB>
+__device__ __forceinline__ void store_units(const floatx16 (&x)[NB], int hl, float* __restrict__ out, bool valid) {
+    if (!valid) return;
+    float* ob = out + 4 * hl;
+    asm volatile("" : "+v"(ob));
+    static_for<0, NB>([&](auto bb) {
+        constexpr int b = decltype(bb)::value;
+        static_for<0, 4>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            *reinterpret_cast<float4*>(ob + 32 * b + 8 * q) =
+                make_float4(x[b][4 * q], x[b][4 * q + 1], x[b][4 * q + 2], x[b][4 * q + 3]);
+        });
+    });
+}
+
+// Backward through y = relu(n g + e), n = LayerNorm-normalised z.  In: d = dL/dy; out: d = dL/dz.  Writes the
+// two per-row terms of the LayerNorm parameter gradients, E = dL/d(n g + e) (its column sum is the gradient of e)
+// and G = E n (column sum: gradient of g), to rowE / rowG.
+template <int NB>
+__device__ __forceinline__ void layer_norm_backward(floatx16 (&d)[NB], const floatx16 (&n)[NB], float rstd,
+                                                    const float* __restrict__ g, const float* __restrict__ e, int hl,
+                                                    float* __restrict__ rowE, float* __restrict__ rowG, bool valid) {
+    constexpr int H = NB * 32;
+    float m1 = 0.0f, m2 = 0.0f;
+    const float* gb = g + opaque(4 * hl);
+    const float* eb = e + opaque(4 * hl);
+    float* oe = rowE + 4 * hl;
+    float* og = rowG + 4 * hl;
+    asm volatile("" : "+v"(oe), "+v"(og));
+    static_for<0, NB>([&](auto bb) {
+        constexpr int b = decltype(bb)::value;
+        static_for<0, 4>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            constexpr int u = 32 * b + 8 * q;
+            const float4 gq = *reinterpret_cast<const float4*>(gb + u);
+            const float4 eq = *reinterpret_cast<const float4*>(eb + u);
+            const float gv[4] = {gq.x, gq.y, gq.z, gq.w}, ev[4] = {eq.x, eq.y, eq.z, eq.w};
+            float E[4], G[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float nv = n[b][4 * q + i];
+                const float on = fmaf(nv, gv[i], ev[i]) > 0.0f ? d[b][4 * q + i] : 0.0f;
+                E[i] = on;
+                G[i] = on * nv;
+                const float dx = on * gv[i];
+                d[b][4 * q + i] = dx;
+                m1 += dx;
+                m2 = fmaf(dx, nv, m2);
+            }
+            if (valid) {
+                *reinterpret_cast<float4*>(oe + u) = make_float4(E[0], E[1], E[2], E[3]);
+                *reinterpret_cast<float4*>(og + u) = make_float4(G[0], G[1], G[2], G[3]);
+            }
+            LDS_FENCE();
+        });
+    });
+    m1 += __shfl_xor(m1, 32);
+    m2 += __shfl_xor(m2, 32);
+    m1 *= 1.0f / H;
+    m2 *= 1.0f / H;
+    static_for<0, NB>([&](auto bb) {
+        static_for<0, 16>([&](auto vv) {
+            constexpr int b = decltype(bb)::value, v = decltype(vv)::value;
+            d[b][v] = rstd * (d[b][v] - m1 - n[b][v] * m2);
+        });
+    });
+}
+
+__device__ __forceinline__ float wave_total(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int H>
+__global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int B, int actor_blocks) {
+    using P = TrainPack<H>;
+    constexpr int NB = P::NB, NS = P::NS, LD = H + 4;
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int hl = lane >> 5, j = lane & 31;
+    const bool actor = (int)blockIdx.x < actor_blocks;
+    {
+        const float4* src = reinterpret_cast<const float4*>(io.weights + (actor ? 0 : P::c_f1));
+        const int n4 = (actor ? P::a_end : P::total - P::c_f1) / 4;
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int i = tid; i < n4; i += PPO_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int tiles = (B + 31) / 32;
+    const float inv_b = 1.0f / (float)B;
+    if (actor) {
+        float s_loss = 0.0f, s_ent = 0.0f, s_clip = 0.0f, s_kl = 0.0f;
+        for (int tile = blockIdx.x * PPO_WAVES + wave; tile < tiles; tile += actor_blocks * PPO_WAVES) {
+            const int p = tile * 32 + j;
+            const bool valid = p < B;
+            const int pp = valid ? p : B - 1;
+            const size_t r = io.index ? (size_t)io.index[pp] : (size_t)pp;
+            const float* o = io.obs + r * OBS;
+            const float o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3], o4 = o[4];
+            const float x0 = hl ? o1 : o0, x1 = hl ? o3 : o2, x2 = hl ? 1.0f : o4;
+            if (valid) {                                     // [obs | 1 | 0 0], shared with the critic's products
+                float4* xe = reinterpret_cast<float4*>(io.xe + (size_t)p * 8);
+                xe[hl] = hl ? make_float4(o4, 1.0f, 0.0f, 0.0f) : make_float4(o0, o1, o2, o3);
+            }
+            floatx16 n1[NB], n2[NB], y[NB];
+            first_layer<NB>(lds + P::a_f1, lane, x0, x1, x2, n1);
+            const float rstd1 = normalise<NB>(n1);
+            affine_relu_store<NB>(n1, lds + P::a_g1, lds + P::a_e1, hl, y, io.y1e + (size_t)p * LD, valid);
+            if (valid && hl == 0) *reinterpret_cast<float4*>(io.y1e + (size_t)p * LD + H) = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+            unit_vector<NB>(lds + P::a_b2, hl, n2);
+            hidden_layer<NB>(lds + P::a_f2, lane, y, n2);
+            const float rstd2 = normalise<NB>(n2);
+            affine_relu_store<NB>(n2, lds + P::a_g2, lds + P::a_e2, hl, y, io.y2e + (size_t)p * LD, valid);
+            if (valid && hl == 0) *reinterpret_cast<float4*>(io.y2e + (size_t)p * LD + H) = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+            // heads
+            floatx16 h0 = {0}, h1 = {0};
+            {
+                const float4 bh = *reinterpret_cast<const float4*>(lds + P::a_bh + 4 * hl);
+                h0[0] = bh.x; h0[1] = bh.y; h0[2] = bh.z; h0[3] = bh.w;
+            }
+            const float* fh = lds + P::a_fh + opaque(lane * 4);
+            static_for<0, NS / 4>([&](auto ss) {
+                constexpr int s4 = decltype(ss)::value;
+                const float4 w = *reinterpret_cast<const float4*>(fh + s4 * 256);
+                h0 = mfma(w.x, y[(4 * s4) / 16][(4 * s4) % 16], h0);
+                h1 = mfma(w.y, y[(4 * s4 + 1) / 16][(4 * s4 + 1) % 16], h1);
+                h0 = mfma(w.z, y[(4 * s4 + 2) / 16][(4 * s4 + 2) % 16], h0);
+                h1 = mfma(w.w, y[(4 * s4 + 3) / 16][(4 * s4 + 3) % 16], h1);
+                LDS_FENCE();
+            });
+            float mine[4], other[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { mine[q] = h0[q] + h1[q]; other[q] = __shfl_xor(mine[q], 32); }
+            const float mu0 = hl ? other[0] : mine[0], mu1 = hl ? other[1] : mine[1];
+            const float rl0 = hl ? other[2] : mine[2], rl1 = hl ? other[3] : mine[3];
+            float lg[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lg[q] = hl ? mine[q] : other[q];
+            // evaluate_actions (actor.py:204-247) and the losses of ppo_agent.py:296-316; every lane of the row's pair
+            // computes the same values
+            const float* act = io.actions + r * 3;
+            const float vlim = 2.0f * io.v_max;
+            const float a0 = fminf(fmaxf(act[0], -vlim), vlim), a1 = fminf(fmaxf(act[1], -vlim), vlim);
+            int band = (int)act[2];
+            band = band < 0 ? 0 : (band > 3 ? 3 : band);
+            const float ls0 = fminf(fmaxf(rl0, io.log_std_min), io.log_std_max), ls1 = fminf(fmaxf(rl1, io.log_std_min), io.log_std_max);
+            const bool in0 = rl0 >= io.log_std_min && rl0 <= io.log_std_max, in1 = rl1 >= io.log_std_min && rl1 <= io.log_std_max;
+            const float is0 = expf(-ls0), is1 = expf(-ls1);
+            const float z0 = (a0 - mu0) * is0, z1 = (a1 - mu1) * is1;
+            const float lmax = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+            float ex[4], esum = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ex[q] = expf(lg[q] - lmax); esum += ex[q]; }
+            const float lse = lmax + logf(esum), ies = 1.0f / esum;
+            float pr[4], lpk[4], hcat = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { pr[q] = ex[q] * ies; lpk[q] = lg[q] - lse; hcat -= pr[q] * lpk[q]; }
+            const float HALF_LOG_2PI = 0.91893853320467274f;
+            const float lp = (-0.5f * z0 * z0 - ls0 - HALF_LOG_2PI) + (-0.5f * z1 * z1 - ls1 - HALF_LOG_2PI) + lpk[band];
+            const float ent = (0.5f + HALF_LOG_2PI + ls0) + (0.5f + HALF_LOG_2PI + ls1) + hcat;
+            const float dlt = lp - io.old_log_probs[r];
+            const float ratio = expf(dlt), adv = io.advantages[r];
+            const float lo = 1.0f - io.clip_eps, hi = 1.0f + io.clip_eps;
+            const float s1 = ratio * adv, s2 = fminf(fmaxf(ratio, lo), hi) * adv;
+            const bool inside = ratio >= lo && ratio <= hi;
+            // d(-min(s1, s2))/d ratio: the unclipped branch when it is the smaller one; on a tie both branches carry
+            // half, and the clipped one passes it on only inside the clip range
+            const float through = s1 < s2 ? 1.0f : (s1 == s2 && inside ? 1.0f : 0.0f);
+            const float glp = valid ? -adv * through * ratio * inv_b : 0.0f;           // dL/d log_prob
+            const float gent = valid ? -io.c2 * inv_b : 0.0f;                            // dL/d entropy
+            float dh[8];
+            dh[0] = glp * z0 * is0;
+            dh[1] = glp * z1 * is1;
+            dh[2] = in0 ? glp * (z0 * z0 - 1.0f) + gent : 0.0f;
+            dh[3] = in1 ? glp * (z1 * z1 - 1.0f) + gent : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dh[4 + q] = glp * ((q == band ? 1.0f : 0.0f) - pr[q]) - gent * pr[q] * (lpk[q] + hcat);
+            if (valid) {
+                float4* out = reinterpret_cast<float4*>(io.dh + (size_t)p * 8);
+                out[hl] = hl ? make_float4(dh[4], dh[5], dh[6], dh[7]) : make_float4(dh[0], dh[1], dh[2], dh[3]);
+                if (hl == 0) {
+                    s_loss -= fminf(s1, s2);
+                    s_ent += ent;
+                    s_clip += fabsf(ratio - 1.0f) > io.clip_eps ? 1.0f : 0.0f;
+                    s_kl += (ratio - 1.0f) - dlt;
+                }
+            }
+            // dL/dy2 = heads^T dh: contraction over the 8 heads, input 2 s + hl in step s
+            floatx16 d[NB];
+            const float* fhT = lds + P::a_fhT + opaque(lane);
+            static_for<0, NB>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                floatx16 c = {0};
+                c = mfma(fhT[(b * 4 + 0) * 64], hl ? dh[1] : dh[0], c);
+                c = mfma(fhT[(b * 4 + 1) * 64], hl ? dh[3] : dh[2], c);
+                c = mfma(fhT[(b * 4 + 2) * 64], hl ? dh[5] : dh[4], c);
+                c = mfma(fhT[(b * 4 + 3) * 64], hl ? dh[7] : dh[6], c);
+                d[b] = c;
+            });
+            layer_norm_backward<NB>(d, n2, rstd2, lds + P::a_g2, lds + P::a_e2, hl, io.le2 + (size_t)p * H,
+                                    io.lg2 + (size_t)p * H, valid);
+            store_units<NB>(d, hl, io.dz2 + (size_t)p * H, valid);
+            // dL/dy1 = W2^T dz2
+            static_for<0, NB>([&](auto bb) { y[decltype(bb)::value] = floatx16{0}; });
+            hidden_layer<NB>(lds + P::a_f2T, lane, d, y);
+            layer_norm_backward<NB>(y, n1, rstd1, lds + P::a_g1, lds + P::a_e1, hl, io.le1 + (size_t)p * H,
+                                    io.lg1 + (size_t)p * H, valid);
+            store_units<NB>(y, hl, io.dz1 + (size_t)p * H, valid);
+        }
+        s_loss = wave_total(s_loss); s_ent = wave_total(s_ent); s_clip = wave_total(s_clip); s_kl = wave_total(s_kl);
+        if (lane == 0 && io.stats) {
+            atomicAdd(io.stats + 0, (double)s_loss);
+            atomicAdd(io.stats + 2, (double)s_ent);
+            atomicAdd(io.stats + 3, (double)s_clip);
+            atomicAdd(io.stats + 4, (double)s_kl);
+        }
+    } else {
+        const int nblocks = gridDim.x - actor_blocks;
+        const float* cf1 = lds;
+        const float* cf2 = lds + (P::c_f2 - P::c_f1);
+        const float* cb2 = lds + (P::c_b2 - P::c_f1);
+        const float* cw3 = lds + (P::c_w3 - P::c_f1);
+        const float cb3 = lds[P::c_b3 - P::c_f1];
+        const float* cf2T = lds + (P::c_f2T - P::c_f1);
+        float s_vloss = 0.0f;
+        for (int tile = ((int)blockIdx.x - actor_blocks) * PPO_WAVES + wave; tile < tiles; tile += nblocks * PPO_WAVES) {
+            const int p = tile * 32 + j;
+            const bool valid = p < B;
+            const int pp = valid ? p : B - 1;
+            const size_t r = io.index ? (size_t)io.index[pp] : (size_t)pp;
+            const float* o = io.obs + r * OBS;
+            const float x0 = o[hl], x1 = o[2 + hl], x2 = hl ? 1.0f : o[4];
+            floatx16 y1[NB], y2[NB];
+            first_layer<NB>(cf1, lane, x0, x1, x2, y1);
+            static_for<0, NB>([&](auto bb) { static_for<0, 16>([&](auto vv) {
+                y1[decltype(bb)::value][decltype(vv)::value] = fmaxf(y1[decltype(bb)::value][decltype(vv)::value], 0.0f); }); });
+            store_units<NB>(y1, hl, io.cy1e + (size_t)p * LD, valid);
+            if (valid && hl == 0) *reinterpret_cast<float4*>(io.cy1e + (size_t)p * LD + H) = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+            unit_vector<NB>(cb2, hl, y2);
+            hidden_layer<NB>(cf2, lane, y1, y2);
+            static_for<0, NB>([&](auto bb) { static_for<0, 16>([&](auto vv) {
+                y2[decltype(bb)::value][decltype(vv)::value] = fmaxf(y2[decltype(bb)::value][decltype(vv)::value], 0.0f); }); });
+            store_units<NB>(y2, hl, io.cy2e + (size_t)p * LD, valid);
+            if (valid && hl == 0) *reinterpret_cast<float4*>(io.cy2e + (size_t)p * LD + H) = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+            float v = 0.0f;
+            const float* w3b = cw3 + opaque(4 * hl);
+            static_for<0, NB>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                static_for<0, 4>([&](auto qq) {
+                    constexpr int q = decltype(qq)::value;
+                    const float4 wq = *reinterpret_cast<const float4*>(w3b + 32 * b + 8 * q);
+                    v = fmaf(wq.x, y2[b][4 * q], v);
+                    v = fmaf(wq.y, y2[b][4 * q + 1], v);
+                    v = fmaf(wq.z, y2[b][4 * q + 2], v);
+                    v = fmaf(wq.w, y2[b][4 * q + 3], v);
+                    LDS_FENCE();
+                });
+            });
+            v += __shfl_xor(v, 32);
+            v += cb3;
+            const float err = v - io.returns[r];
+            const float dv = valid ? 2.0f * io.c1 * err * inv_b : 0.0f;                 // d(c1 mean (v - ret)^2)/dv
+            if (valid && hl == 0) {
+                io.dv[p] = dv;
+                s_vloss = fmaf(io.c1 * err, err, s_vloss);
+            }
+            // dz2 = w3 dv where y2 > 0; dy1 = W2^T dz2; dz1 = dy1 where y1 > 0
+            static_for<0, NB>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                static_for<0, 4>([&](auto qq) {
+                    constexpr int q = decltype(qq)::value;
+                    const float4 wq = *reinterpret_cast<const float4*>(w3b + 32 * b + 8 * q);
+                    y2[b][4 * q] = y2[b][4 * q] > 0.0f ? wq.x * dv : 0.0f;
+                    y2[b][4 * q + 1] = y2[b][4 * q + 1] > 0.0f ? wq.y * dv : 0.0f;
+                    y2[b][4 * q + 2] = y2[b][4 * q + 2] > 0.0f ? wq.z * dv : 0.0f;
+                    y2[b][4 * q + 3] = y2[b][4 * q + 3] > 0.0f ? wq.w * dv : 0.0f;
+                    LDS_FENCE();
+                });
+            });
+            store_units<NB>(y2, hl, io.cdz2 + (size_t)p * H, valid);
+            floatx16 dy[NB];
+            static_for<0, NB>([&](auto bb) { dy[decltype(bb)::value] = floatx16{0}; });
+            hidden_layer<NB>(cf2T, lane, y2, dy);
+            static_for<0, NB>([&](auto bb) { static_for<0, 16>([&](auto vv) {
+                constexpr int b = decltype(bb)::value, q = decltype(vv)::value;
+                dy[b][q] = y1[b][q] > 0.0f ? dy[b][q] : 0.0f; }); });
+            store_units<NB>(dy, hl, io.cdz1 + (size_t)p * H, valid);
+        }
+        s_vloss = wave_total(s_vloss);
+        if (lane == 0 && io.stats) atomicAdd(io.stats + 1, (double)s_vloss);
+    }
+}
+
+int g_ppo_cus = 0;
+
+}  // namespace
+
+extern "C" __attribute__((visibility("hidden"))) void marl_note_hip_error(int err);     // marl_env.hip
+
+extern "C" {
+
+size_t marl_ppo_weight_count(int32_t hidden) {
+    switch (hidden) {
+        case 64: return TrainPack<64>::total;
+        case 128: return TrainPack<128>::total;
+        default: return 0;
+    }
+}
+
+int marl_ppo_rows(int32_t B, int32_t hidden, const MarlPpoIO* io, void* stream) {
+    if (io == nullptr || B < 1) return MARL_EINVAL;
+    if (hidden != 64 && hidden != 128) return MARL_EUNSUPPORTED;
+    if (io->weights == nullptr || io->obs == nullptr || io->actions == nullptr || io->old_log_probs == nullptr ||
+        io->advantages == nullptr || io->returns == nullptr || io->xe == nullptr || io->y1e == nullptr ||
+        io->y2e == nullptr || io->dz1 == nullptr || io->le1 == nullptr || io->lg1 == nullptr || io->dz2 == nullptr ||
+        io->le2 == nullptr || io->lg2 == nullptr || io->dh == nullptr || io->cy1e == nullptr ||
+        io->cy2e == nullptr || io->cdz1 == nullptr || io->cdz2 == nullptr || io->dv == nullptr)
+        return MARL_EINVAL;
+    if (g_ppo_cus == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 2)
+            cus = 256;
+        g_ppo_cus = cus;
+    }
+    const int tiles = (B + 31) / 32;
+    int grid = g_ppo_cus;
+    if (2 * tiles < grid * PPO_WAVES) grid = (2 * tiles + PPO_WAVES - 1) / PPO_WAVES;
+    if (grid < 2) grid = 2;
+    // matrix instructions per tile: actor 3 layers forward + heads^T + W2^T, critic 2 layers forward + W2^T
+    const double wa = hidden / 32 * 3 + hidden / 32 * hidden / 2 * 2 + hidden / 2 + hidden / 32 * 4;
+    const double wc = hidden / 32 * 3 + hidden / 32 * hidden / 2 * 2;
+    int actor_blocks = (int)(grid * wa / (wa + wc) + 0.5);
+    if (actor_blocks < 1) actor_blocks = 1;
+    if (actor_blocks > grid - 1) actor_blocks = grid - 1;
+    hipError_t err = hipSuccess;
+#define MARL_LAUNCH_PPO(HH)                                                                                          \
+    do {                                                                                                              \
+        static bool attr_set = false;                                                                                 \
+        const size_t lds_bytes = (size_t)TrainPack<HH>::lds_floats * sizeof(float);                                   \
+        if (!attr_set) {                                                                                              \
+            err = hipFuncSetAttribute((const void*)ppo_rows_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                      (int)lds_bytes);                                                                \
+            attr_set = err == hipSuccess;                                                                             \
+        }                                                                                                             \
+        if (err == hipSuccess)                                                                                        \
+            hipLaunchKernelGGL(ppo_rows_kernel<HH>, dim3(grid), dim3(PPO_THREADS), lds_bytes, (hipStream_t)stream, *io, \
+                               (int)B, actor_blocks);                                                                 \
+    } while (0)
+    if (hidden == 64) MARL_LAUNCH_PPO(64); else MARL_LAUNCH_PPO(128);
+#undef MARL_LAUNCH_PPO
+    if (err == hipSuccess) err = hipGetLastError();
+    if (err == hipSuccess) return MARL_OK;
+    marl_note_hip_error((int)err);
+    return MARL_EHIP;
+}
+
+}  // extern "C"

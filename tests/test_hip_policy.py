@@ -99,7 +99,7 @@ def test_update_graph_is_limited_to_minibatches_where_replay_equals_eager():
     """The captured minibatch step is used up to PPOAgent.GRAPH_MAX_BATCH rows; at that size every replay
     gives the weights of the eager step."""
     B = PPOAgent.GRAPH_MAX_BATCH
-    a = PPOAgent(device="cuda", M=4, batch_size=B, n_epochs=1, seed=1, graph_update=False)
+    a = PPOAgent(device="cuda", M=4, batch_size=B, n_epochs=1, seed=1, graph_update=False, fused_update=False)
     b = PPOAgent(device="cuda", M=4, batch_size=B, n_epochs=1, seed=1, graph_update=True)
     big = PPOAgent(device="cuda", M=4, batch_size=4 * B, seed=1, graph_update=True)
     assert b._graph_update and not a._graph_update and not big._graph_update
