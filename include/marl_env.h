@@ -322,8 +322,9 @@ int marl_policy_act(int32_t E, int32_t M, int32_t hidden, float v_max, float log
  * and the backward pass down to every layer's pre-activation, one minibatch row per lane on the matrix cores.
  * The gradient of a parameter is then a product of two of the [B][.] matrices written here (the 1/B of the means
  * is already applied):
- *   actor   trunk.0 [W | b] = dz1^T xe[:, :6]      trunk.1 (LayerNorm) bias = colsum le1, weight = colsum lg1
- *           trunk.3 [W | b] = dz2^T y1e[:, :H+1]   trunk.4 bias = colsum le2, weight = colsum lg2
+ *   actor   trunk.0 [W | b] = dz1^T xe[:, :6]      trunk.3 [W | b] = dz2^T y1e[:, :H+1]
+ *           LayerNorm weights and biases: ln_sums summed over its first dimension (summed in the kernel: a
+ *           reduce-scatter over the 32 rows of a tile, then per-wave running sums)
  *           heads   [W | b] = dh^T y2e[:, :H+1]          (rows: mu 0-1, log_std 2-3, band 4-7)
  *   critic  network.0 [W | b] = cdz1^T xe[:, :6]   network.2 [W | b] = cdz2^T cy1e[:, :H+1]   network.4 [W | b] = dv^T cy2e[:, :H+1]
  * `stats` (float64 [5], added to): sums over the rows of the actor loss term, c1 (V - R)^2, the entropy, the
@@ -344,8 +345,10 @@ typedef struct MarlPpoIO {
     const int64_t *index;        /* [B] rows of the minibatch; NULL = rows 0 .. B-1 */
     float *xe;                   /* [B][8]    out: obs, 1, 0, 0 */
     float *y1e, *y2e;            /* [B][H+4]  out: actor activations after each LayerNorm + ReLU, then 1, 0, 0, 0 */
-    float *dz1, *le1, *lg1;      /* [B][H]    out, actor layer 1: dL/dz, dL/d(LayerNorm output), the same times the normalised z */
-    float *dz2, *le2, *lg2;      /* [B][H]    out, actor layer 2 */
+    float *dz1, *dz2;            /* [B][H]    out: actor dL/dz per layer */
+    float *ln_sums;              /* [marl_ppo_ln_rows()][4][H] out: per wave, the sums over its rows of (dL/d(LayerNorm 1
+                                    output), the same times the normalised z, and both for LayerNorm 2); the sum over the
+                                    first dimension is the gradient of (trunk.1.bias, trunk.1.weight, trunk.4.bias, trunk.4.weight) */
     float *dh;                   /* [B][8]    out: dL/d(head outputs) */
     float *cy1e, *cy2e;          /* [B][H+4]  out: critic activations, then 1, 0, 0, 0 */
     float *cdz1, *cdz2;          /* [B][H]    out: critic dL/dz per layer */
@@ -354,6 +357,7 @@ typedef struct MarlPpoIO {
     float clip_eps, c1, c2, v_max, log_std_min, log_std_max;
 } MarlPpoIO;
 size_t marl_ppo_weight_count(int32_t hidden);
+int32_t marl_ppo_ln_rows(void);
 int marl_ppo_rows(int32_t B, int32_t hidden, const MarlPpoIO *io, void *stream);
 
 /* The enemy-noise draw the step kernel uses when MarlStepIO.noise is NULL,

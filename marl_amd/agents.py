@@ -595,9 +595,9 @@ class PPOAgent:
         z = self._fz
         if z["B"] < B:
             f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=self.device)
-            z.update(B=B, xe=f(B, 8), y1e=f(B, H + 4), y2e=f(B, H + 4), dz1=f(B, H), le1=f(B, H), lg1=f(B, H),
-                     dz2=f(B, H), le2=f(B, H), lg2=f(B, H), dh=f(B, 8), cy1e=f(B, H + 4), cy2e=f(B, H + 4),
-                     cdz1=f(B, H), cdz2=f(B, H), dv=f(B))
+            z.update(B=B, xe=f(B, 8), y1e=f(B, H + 4), y2e=f(B, H + 4), dz1=f(B, H), dz2=f(B, H), dh=f(B, 8),
+                     cy1e=f(B, H + 4), cy2e=f(B, H + 4), cdz1=f(B, H), cdz2=f(B, H), dv=f(B),
+                     ln_sums=f(_lib.load().marl_ppo_ln_rows(), 4, H))
         return z
 
     def _fused_forward_backward(self, obs, actions, old_log_probs, advantages, returns, idx) -> torch.Tensor:
@@ -612,7 +612,7 @@ class PPOAgent:
         io.weights = weights.data_ptr()
         io.obs, io.actions, io.old_log_probs = obs.data_ptr(), actions.data_ptr(), old_log_probs.data_ptr()
         io.advantages, io.returns, io.index = advantages.data_ptr(), returns.data_ptr(), idx.data_ptr()
-        for k in ("xe", "y1e", "y2e", "dz1", "le1", "lg1", "dz2", "le2", "lg2", "dh", "cy1e", "cy2e", "cdz1", "cdz2", "dv"):
+        for k in ("xe", "y1e", "y2e", "dz1", "dz2", "ln_sums", "dh", "cy1e", "cy2e", "cdz1", "cdz2", "dv"):
             setattr(io, k, z[k].data_ptr())
         io.stats = z["stats"].data_ptr()
         io.clip_eps, io.c1, io.c2, io.v_max = float(self.clip_eps), float(self.c1), float(self.c2), float(self.v_max)
@@ -628,10 +628,6 @@ class PPOAgent:
                 return torch.bmm(a.view(s, B // s, -1).transpose(1, 2), b.view(s, B // s, -1)).sum(0)
             return a.t() @ b
 
-        def colsum(a):
-            a = a[:B]
-            return a.view(s, B // s, -1).sum(1).sum(0) if s > 1 else a.sum(0)
-
         t, n = self.actor.trunk, self.critic.network
         g1 = rows_product(z["dz1"], z["xe"])
         g2 = rows_product(z["dz2"], z["y1e"])
@@ -639,8 +635,9 @@ class PPOAgent:
         c1 = rows_product(z["cdz1"], z["xe"])
         c2 = rows_product(z["cdz2"], z["cy1e"])
         c3 = rows_product(z["dv"].view(-1, 1), z["cy2e"])
-        grads = [(t[0].weight, g1[:, :5]), (t[0].bias, g1[:, 5]), (t[1].weight, colsum(z["lg1"])), (t[1].bias, colsum(z["le1"])),
-                 (t[3].weight, g2[:, :H]), (t[3].bias, g2[:, H]), (t[4].weight, colsum(z["lg2"])), (t[4].bias, colsum(z["le2"])),
+        ln = z["ln_sums"].sum(0)                                          # (bias 1, weight 1, bias 2, weight 2) x H
+        grads = [(t[0].weight, g1[:, :5]), (t[0].bias, g1[:, 5]), (t[1].weight, ln[1]), (t[1].bias, ln[0]),
+                 (t[3].weight, g2[:, :H]), (t[3].bias, g2[:, H]), (t[4].weight, ln[3]), (t[4].bias, ln[2]),
                  (self.actor.mu_head.weight, gh[0:2, :H]), (self.actor.mu_head.bias, gh[0:2, H]),
                  (self.actor.log_std_head.weight, gh[2:4, :H]), (self.actor.log_std_head.bias, gh[2:4, H]),
                  (self.actor.band_head.weight, gh[4:8, :H]), (self.actor.band_head.bias, gh[4:8, H]),

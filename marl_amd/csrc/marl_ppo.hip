@@ -23,6 +23,9 @@ constexpr int WAVE = 64;
 constexpr int OBS = MARL_OBS_DIM;
 constexpr int PPO_THREADS = 512;
 constexpr int PPO_WAVES = PPO_THREADS / WAVE;
+#ifndef PPO_STORE_ROWS
+#define PPO_STORE_ROWS true      // false (experiments only): the row pass without its stores
+#endif
 
 // Offsets (in floats) of the packed training weights, see marl_ppo_weight_count in marl_env.h.
 template <int H>
@@ -118,46 +121,72 @@ __device__ __forceinline__ void store_units(const floatx16 (&x)[NB], int hl, flo
     });
 }
 
-// Backward through y = relu(n g + e), n = LayerNorm-normalised z.  In: d = dL/dy; out: d = dL/dz.  Writes the
-// two per-row terms of the LayerNorm parameter gradients, E = dL/d(n g + e) (its column sum is the gradient of e)
-// and G = E n (column sum: gradient of g), to rowE / rowG.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+template <int PATTERN>
+__device__ __forceinline__ float swizzle_f(float x) {
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), PATTERN));
+}
+// Sums, over the 32 lanes of a half wave, of 16 values per lane -- as a reduce-scatter: each exchange halves the
+// values a lane still carries (lane ^ 1, ^ 2, ^ 4, ^ 8), so 15 exchanges do what 16 separate reductions would need
+// 64 for.  Lane j ends with the total of value 8 (j & 1) + 4 (j >> 1 & 1) + 2 (j >> 2 & 1) + (j >> 3 & 1); lanes j
+// and j ^ 16 hold the same total.
+__device__ __forceinline__ float reduce_scatter16(const float (&x)[16], int j) {
+    const bool b0 = j & 1, b1 = j & 2, b2 = j & 4, b3 = j & 8;
+    float y[8], z[4], w[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = (b0 ? x[i + 8] : x[i]) + dpp_f<0xB1>(b0 ? x[i] : x[i + 8]);          // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = (b1 ? y[i + 4] : y[i]) + dpp_f<0x4E>(b1 ? y[i] : y[i + 4]);          // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w[i] = (b2 ? z[i + 2] : z[i]) + swizzle_f<0x101F>(b2 ? z[i] : z[i + 2]);    // lane ^ 4
+    float r = (b3 ? w[1] : w[0]) + dpp_f<0x128>(b3 ? w[0] : w[1]);                                           // row_ror:8 = lane ^ 8
+    return r + swizzle_f<0x401F>(r);                                                                         // lane ^ 16
+}
+// The unit whose total reduce_scatter16 leaves in lane j of half hl, for accumulator block b.
+__device__ __forceinline__ int scattered_unit(int b, int j, int hl) {
+    const int v = 8 * (j & 1) + 4 * ((j >> 1) & 1) + 2 * ((j >> 2) & 1) + ((j >> 3) & 1);
+    return unit_of(b, v, hl);
+}
+
+// Backward through y = relu(n g + e), n = LayerNorm-normalised z.  In: d = dL/dy; out: d = dL/dz.  The two
+// per-row terms of the LayerNorm parameter gradients, E = dL/d(n g + e) (summed over the rows: the gradient of
+// e) and G = E n (gradient of g), are summed over the 32 rows of the tile and added to accE / accG, one unit per
+// lane and block (scattered_unit); rows beyond the minibatch carry d = 0.
 template <int NB>
 __device__ __forceinline__ void layer_norm_backward(floatx16 (&d)[NB], const floatx16 (&n)[NB], float rstd,
-                                                    const float* __restrict__ g, const float* __restrict__ e, int hl,
-                                                    float* __restrict__ rowE, float* __restrict__ rowG, bool valid) {
+                                                    const float* __restrict__ g, const float* __restrict__ e, int hl, int j,
+                                                    float (&accE)[NB], float (&accG)[NB]) {
     constexpr int H = NB * 32;
     float m1 = 0.0f, m2 = 0.0f;
     const float* gb = g + opaque(4 * hl);
     const float* eb = e + opaque(4 * hl);
-    float* oe = rowE + 4 * hl;
-    float* og = rowG + 4 * hl;
-    asm volatile("" : "+v"(oe), "+v"(og));
     static_for<0, NB>([&](auto bb) {
         constexpr int b = decltype(bb)::value;
+        float E[16], G[16];
         static_for<0, 4>([&](auto qq) {
             constexpr int q = decltype(qq)::value;
             constexpr int u = 32 * b + 8 * q;
             const float4 gq = *reinterpret_cast<const float4*>(gb + u);
             const float4 eq = *reinterpret_cast<const float4*>(eb + u);
             const float gv[4] = {gq.x, gq.y, gq.z, gq.w}, ev[4] = {eq.x, eq.y, eq.z, eq.w};
-            float E[4], G[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float nv = n[b][4 * q + i];
                 const float on = fmaf(nv, gv[i], ev[i]) > 0.0f ? d[b][4 * q + i] : 0.0f;
-                E[i] = on;
-                G[i] = on * nv;
+                E[4 * q + i] = on;
+                G[4 * q + i] = on * nv;
                 const float dx = on * gv[i];
                 d[b][4 * q + i] = dx;
                 m1 += dx;
                 m2 = fmaf(dx, nv, m2);
             }
-            if (valid) {
-                *reinterpret_cast<float4*>(oe + u) = make_float4(E[0], E[1], E[2], E[3]);
-                *reinterpret_cast<float4*>(og + u) = make_float4(G[0], G[1], G[2], G[3]);
-            }
-            LDS_FENCE();
         });
+        accE[b] += reduce_scatter16(E, j);
+        accG[b] += reduce_scatter16(G, j);
+        LDS_FENCE();
     });
     m1 += __shfl_xor(m1, 32);
     m2 += __shfl_xor(m2, 32);
@@ -196,9 +225,10 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int
     const float inv_b = 1.0f / (float)B;
     if (actor) {
         float s_loss = 0.0f, s_ent = 0.0f, s_clip = 0.0f, s_kl = 0.0f;
+        float acc_e1[NB] = {}, acc_g1[NB] = {}, acc_e2[NB] = {}, acc_g2[NB] = {};      // LayerNorm parameter gradients
         for (int tile = blockIdx.x * PPO_WAVES + wave; tile < tiles; tile += actor_blocks * PPO_WAVES) {
             const int p = tile * 32 + j;
-            const bool valid = p < B;
+            const bool valid = PPO_STORE_ROWS && p < B;
             const int pp = valid ? p : B - 1;
             const size_t r = io.index ? (size_t)io.index[pp] : (size_t)pp;
             const float* o = io.obs + r * OBS;
@@ -303,15 +333,21 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int
                 c = mfma(fhT[(b * 4 + 3) * 64], hl ? dh[7] : dh[6], c);
                 d[b] = c;
             });
-            layer_norm_backward<NB>(d, n2, rstd2, lds + P::a_g2, lds + P::a_e2, hl, io.le2 + (size_t)p * H,
-                                    io.lg2 + (size_t)p * H, valid);
+            layer_norm_backward<NB>(d, n2, rstd2, lds + P::a_g2, lds + P::a_e2, hl, j, acc_e2, acc_g2);
             store_units<NB>(d, hl, io.dz2 + (size_t)p * H, valid);
             // dL/dy1 = W2^T dz2
             static_for<0, NB>([&](auto bb) { y[decltype(bb)::value] = floatx16{0}; });
             hidden_layer<NB>(lds + P::a_f2T, lane, d, y);
-            layer_norm_backward<NB>(y, n1, rstd1, lds + P::a_g1, lds + P::a_e1, hl, io.le1 + (size_t)p * H,
-                                    io.lg1 + (size_t)p * H, valid);
+            layer_norm_backward<NB>(y, n1, rstd1, lds + P::a_g1, lds + P::a_e1, hl, j, acc_e1, acc_g1);
             store_units<NB>(y, hl, io.dz1 + (size_t)p * H, valid);
+        }
+        if ((j & 16) == 0) {                  // this wave's sums over its tiles: (bias 1, weight 1, bias 2, weight 2) x H
+            float* out = io.ln_sums + (size_t)(blockIdx.x * PPO_WAVES + wave) * 4 * H;
+            static_for<0, NB>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                const int u = scattered_unit(b, j, hl);
+                out[u] = acc_e1[b]; out[H + u] = acc_g1[b]; out[2 * H + u] = acc_e2[b]; out[3 * H + u] = acc_g2[b];
+            });
         }
         s_loss = wave_total(s_loss); s_ent = wave_total(s_ent); s_clip = wave_total(s_clip); s_kl = wave_total(s_kl);
         if (lane == 0 && io.stats) {
@@ -331,7 +367,7 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int
         float s_vloss = 0.0f;
         for (int tile = ((int)blockIdx.x - actor_blocks) * PPO_WAVES + wave; tile < tiles; tile += nblocks * PPO_WAVES) {
             const int p = tile * 32 + j;
-            const bool valid = p < B;
+            const bool valid = PPO_STORE_ROWS && p < B;
             const int pp = valid ? p : B - 1;
             const size_t r = io.index ? (size_t)io.index[pp] : (size_t)pp;
             const float* o = io.obs + r * OBS;
@@ -413,23 +449,29 @@ size_t marl_ppo_weight_count(int32_t hidden) {
     }
 }
 
-int marl_ppo_rows(int32_t B, int32_t hidden, const MarlPpoIO* io, void* stream) {
-    if (io == nullptr || B < 1) return MARL_EINVAL;
-    if (hidden != 64 && hidden != 128) return MARL_EUNSUPPORTED;
-    if (io->weights == nullptr || io->obs == nullptr || io->actions == nullptr || io->old_log_probs == nullptr ||
-        io->advantages == nullptr || io->returns == nullptr || io->xe == nullptr || io->y1e == nullptr ||
-        io->y2e == nullptr || io->dz1 == nullptr || io->le1 == nullptr || io->lg1 == nullptr || io->dz2 == nullptr ||
-        io->le2 == nullptr || io->lg2 == nullptr || io->dh == nullptr || io->cy1e == nullptr ||
-        io->cy2e == nullptr || io->cdz1 == nullptr || io->cdz2 == nullptr || io->dv == nullptr)
-        return MARL_EINVAL;
+static int ppo_cus() {
     if (g_ppo_cus == 0) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 2)
             cus = 256;
         g_ppo_cus = cus;
     }
+    return g_ppo_cus;
+}
+
+int32_t marl_ppo_ln_rows(void) { return ppo_cus() * PPO_WAVES; }
+
+int marl_ppo_rows(int32_t B, int32_t hidden, const MarlPpoIO* io, void* stream) {
+    if (io == nullptr || B < 1) return MARL_EINVAL;
+    if (hidden != 64 && hidden != 128) return MARL_EUNSUPPORTED;
+    if (io->weights == nullptr || io->obs == nullptr || io->actions == nullptr || io->old_log_probs == nullptr ||
+        io->advantages == nullptr || io->returns == nullptr || io->xe == nullptr || io->y1e == nullptr ||
+        io->y2e == nullptr || io->dz1 == nullptr || io->dz2 == nullptr || io->ln_sums == nullptr ||
+        io->dh == nullptr || io->cy1e == nullptr ||
+        io->cy2e == nullptr || io->cdz1 == nullptr || io->cdz2 == nullptr || io->dv == nullptr)
+        return MARL_EINVAL;
     const int tiles = (B + 31) / 32;
-    int grid = g_ppo_cus;
+    int grid = ppo_cus();
     if (2 * tiles < grid * PPO_WAVES) grid = (2 * tiles + PPO_WAVES - 1) / PPO_WAVES;
     if (grid < 2) grid = 2;
     // matrix instructions per tile: actor 3 layers forward + heads^T + W2^T, critic 2 layers forward + W2^T
@@ -438,7 +480,8 @@ int marl_ppo_rows(int32_t B, int32_t hidden, const MarlPpoIO* io, void* stream) 
     int actor_blocks = (int)(grid * wa / (wa + wc) + 0.5);
     if (actor_blocks < 1) actor_blocks = 1;
     if (actor_blocks > grid - 1) actor_blocks = grid - 1;
-    hipError_t err = hipSuccess;
+    // waves that do not run leave their rows of the partial sums at zero
+    hipError_t err = hipMemsetAsync(io->ln_sums, 0, (size_t)marl_ppo_ln_rows() * 4 * hidden * sizeof(float), (hipStream_t)stream);
 #define MARL_LAUNCH_PPO(HH)                                                                                          \
     do {                                                                                                              \
         static bool attr_set = false;                                                                                 \

@@ -32,7 +32,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.MarlStepIO) == 13 * 8
     assert C.sizeof(_lib.MarlPolicyIO) == 9 * 8
     assert C.sizeof(_lib.MarlResetIO) == 11 * 8
-    assert C.sizeof(_lib.MarlPpoIO) == 23 * 8 + 6 * 4
+    assert C.sizeof(_lib.MarlPpoIO) == 20 * 8 + 6 * 4
 
 
 @pytest.mark.parametrize("cfg", [EnvConfig.fast_preset(), EnvConfig(),
