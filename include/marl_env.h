@@ -360,6 +360,16 @@ size_t marl_ppo_weight_count(int32_t hidden);
 int32_t marl_ppo_ln_rows(void);
 int marl_ppo_rows(int32_t B, int32_t hidden, const MarlPpoIO *io, void *stream);
 
+/* The six row products above in one pass over what marl_ppo_rows wrote (same io; only its out pointers are read).
+ * `partial`: [marl_ppo_partial_rows()][marl_ppo_partial_floats(hidden)] out, one slab per workgroup, to be summed
+ * over the first dimension.  A slab, with LDO = 32 ceil((H + 4) / 32):
+ *   actor : dz2^T y1e [H][LDO], dz1^T xe [H][32], dh^T y2e [32][LDO] (rows 0..7)
+ *   critic: cdz2^T cy1e [H][LDO], cdz1^T xe [H][32], dv^T cy2e [32][LDO] (row 0)
+ * Columns beyond H + 4 (and beyond 8 for xe) are zero. */
+int32_t marl_ppo_partial_rows(void);
+size_t marl_ppo_partial_floats(int32_t hidden);
+int marl_ppo_products(int32_t B, int32_t hidden, const MarlPpoIO *io, float *partial, void *stream);
+
 /* The enemy-noise draw the step kernel uses when MarlStepIO.noise is NULL,
  * written out as [E][N][2] for step numbers step_count[e] + 1. */
 int marl_fill_noise(const MarlEnvParams *p, const MarlEnvState *s, uint64_t seed,

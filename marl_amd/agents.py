@@ -598,6 +598,8 @@ class PPOAgent:
             z.update(B=B, xe=f(B, 8), y1e=f(B, H + 4), y2e=f(B, H + 4), dz1=f(B, H), dz2=f(B, H), dh=f(B, 8),
                      cy1e=f(B, H + 4), cy2e=f(B, H + 4), cdz1=f(B, H), cdz2=f(B, H), dv=f(B),
                      ln_sums=f(_lib.load().marl_ppo_ln_rows(), 4, H))
+            if "partial" not in z:
+                z["partial"] = f(_lib.load().marl_ppo_partial_rows(), _lib.load().marl_ppo_partial_floats(H))
         return z
 
     def _fused_forward_backward(self, obs, actions, old_log_probs, advantages, returns, idx) -> torch.Tensor:
@@ -620,21 +622,24 @@ class PPOAgent:
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().marl_ppo_rows(B, H, C.byref(io), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                        "marl_ppo_rows")
-        s = _split_k(B)
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.marl_ppo_products(B, H, C.byref(io), z["partial"].data_ptr(),
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "marl_ppo_products")
+        # one slab per workgroup -> their sum; then cut into the six products (include/marl_env.h)
+        tot = z["partial"].sum(0)
+        LDO = 32 * ((H + 4 + 31) // 32)
+        half = H * LDO + H * 32 + 32 * LDO
 
-        def rows_product(a, b):            # a [>=B, m], b [>=B, n] -> a[:B]^T b[:B], split over row chunks when tall
-            a, b = a[:B], b[:B]
-            if s > 1:
-                return torch.bmm(a.view(s, B // s, -1).transpose(1, 2), b.view(s, B // s, -1)).sum(0)
-            return a.t() @ b
+        def cut(base):
+            g2 = tot[base:base + H * LDO].view(H, LDO)
+            g1 = tot[base + H * LDO:base + H * LDO + H * 32].view(H, 32)
+            gh = tot[base + H * LDO + H * 32:base + half].view(32, LDO)
+            return g1, g2, gh
 
+        g1, g2, gh = cut(0)
+        c1, c2, c3 = cut(half)
         t, n = self.actor.trunk, self.critic.network
-        g1 = rows_product(z["dz1"], z["xe"])
-        g2 = rows_product(z["dz2"], z["y1e"])
-        gh = rows_product(z["dh"], z["y2e"])
-        c1 = rows_product(z["cdz1"], z["xe"])
-        c2 = rows_product(z["cdz2"], z["cy1e"])
-        c3 = rows_product(z["dv"].view(-1, 1), z["cy2e"])
         ln = z["ln_sums"].sum(0)                                          # (bias 1, weight 1, bias 2, weight 2) x H
         grads = [(t[0].weight, g1[:, :5]), (t[0].bias, g1[:, 5]), (t[1].weight, ln[1]), (t[1].bias, ln[0]),
                  (t[3].weight, g2[:, :H]), (t[3].bias, g2[:, H]), (t[4].weight, ln[3]), (t[4].bias, ln[2]),
@@ -642,7 +647,7 @@ class PPOAgent:
                  (self.actor.log_std_head.weight, gh[2:4, :H]), (self.actor.log_std_head.bias, gh[2:4, H]),
                  (self.actor.band_head.weight, gh[4:8, :H]), (self.actor.band_head.bias, gh[4:8, H]),
                  (n[0].weight, c1[:, :5]), (n[0].bias, c1[:, 5]), (n[2].weight, c2[:, :H]), (n[2].bias, c2[:, H]),
-                 (n[4].weight, c3[:, :H]), (n[4].bias, c3[:, H])]
+                 (n[4].weight, c3[0:1, :H]), (n[4].bias, c3[0:1, H])]
         for p, g in grads:
             if p.grad is None:
                 p.grad = torch.empty_like(p)

@@ -433,6 +433,129 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Sums over rows: the six products (row matrix)^T (row matrix) that turn what ppo_rows_kernel wrote into parameter
+// gradients, in ONE pass over the arrays.  The arrays are row-major [B][.], which is the operand layout a
+// contraction over rows wants: step s of a product takes rows 2 s and 2 s + 1, lane l the element of row
+// 2 s + l / 32 in column 32 block + l % 32 -- two full 128-byte lines per load.  A workgroup owns a run of rows;
+// waves 0..3 take the actor's products (wave w: row block w of dz2^T y1e and dz1^T xe, column block w of dh^T y2e),
+// waves 4..7 the critic's; each workgroup leaves its partial 32 x 32 blocks in `partial`, summed by the caller.
+template <int H>
+struct ProductLayout {
+    static constexpr int NBO = H / 32, NBJ = (H + 4 + 31) / 32, LDO = NBJ * 32;
+    static constexpr int g2 = 0;                          // [H][LDO]   dz2^T y1e
+    static constexpr int g1 = g2 + H * LDO;               // [H][32]    dz1^T xe
+    static constexpr int gh = g1 + H * 32;                // [32][LDO]  dh^T y2e (rows 0..7)
+    static constexpr int half = gh + 32 * LDO;            // the critic's three follow in the same order
+    static constexpr int total = 2 * half;
+};
+
+__device__ __forceinline__ void store_block(const floatx16& c, float* __restrict__ out, int ldo, int lane) {
+    const int j = lane & 31, hl = lane >> 5;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) out[(size_t)(8 * (v / 4) + 4 * hl + v % 4) * ldo + j] = c[v];
+}
+
+// One wave's share of the products, specialised on what the wave owns so that the loops carry no conditions:
+// ROWS = row block w of the two hidden-layer products, FIRST / SECOND = column blocks w and w + 4 of the head product.
+template <int H, bool ROWS, bool FIRST, bool SECOND>
+__device__ __forceinline__ void products_body(const MarlPpoIO& io, int B, float* __restrict__ out, int w, bool critic, int lane,
+                                              int s0, int s1) {
+    using L = ProductLayout<H>;
+    constexpr int NBJ = L::NBJ, LD = H + 4, U = 4;
+    const int i = lane & 31, kh = lane >> 5;
+    const float* dzb = critic ? io.cdz2 : io.dz2;          // [B][H]
+    const float* dza = critic ? io.cdz1 : io.dz1;          // [B][H]
+    const float* y1 = critic ? io.cy1e : io.y1e;           // [B][LD]
+    const float* y2 = critic ? io.cy2e : io.y2e;           // [B][LD]
+    const float* hd = critic ? io.dv : io.dh;              // critic: [B] (one head), actor: [B][8]
+    const int heads = critic ? 1 : 8, hstride = critic ? 1 : 8;
+    floatx16 acc2[NBJ], acc1 = {0}, acch0 = {0}, acch1 = {0};
+    static_for<0, NBJ>([&](auto cc) { acc2[decltype(cc)::value] = floatx16{0}; });
+    // Loads carry no branches: addresses are clamped into the arrays, and what lies beyond the minibatch or beyond a
+    // row's columns is zeroed through the A operand or the column masks.
+    const int hcol = i < heads ? i : 0, xcol = i < 8 ? i : 0;
+    const float hmask = i < heads ? 1.0f : 0.0f, xmask = i < 8 ? 1.0f : 0.0f;
+    int ycol[NBJ];
+    float ymask[NBJ];
+    static_for<0, NBJ>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        ycol[c] = 32 * c + i < LD ? 32 * c + i : LD - 1;
+        ymask[c] = 32 * c + i < LD ? 1.0f : 0.0f;
+    });
+    const int hc0 = 32 * w + i, hc1 = 32 * (w + 4) + i;      // this wave's columns of the head product
+    const int hcol0 = hc0 < LD ? hc0 : LD - 1, hcol1 = hc1 < LD ? hc1 : LD - 1;
+    const float hm0 = hc0 < LD ? 1.0f : 0.0f, hm1 = hc1 < LD ? 1.0f : 0.0f;
+    // Software pipeline: the loads of batch n + 1 (U steps) are in flight while the matrix instructions of batch n run.
+    struct Batch { float ah[U], bh0[U], bh1[U], a2[U], a1[U], bx[U], by[U][NBJ]; };
+    auto load = [&](int sb, Batch& t) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = 2 * (sb + u) + kh;
+            const bool ok = sb + u < s1 && r < B;
+            const size_t rr = ok ? (size_t)r : (size_t)(B - 1);
+            const float live = ok ? 1.0f : 0.0f;
+            if constexpr (FIRST || SECOND) t.ah[u] = hd[rr * hstride + hcol] * (hmask * live);
+            if constexpr (FIRST) t.bh0[u] = y2[rr * LD + hcol0] * hm0;
+            if constexpr (SECOND) t.bh1[u] = y2[rr * LD + hcol1] * hm1;
+            if constexpr (ROWS) {
+                t.a2[u] = dzb[rr * H + 32 * w + i] * live;
+                t.a1[u] = dza[rr * H + 32 * w + i] * live;
+                t.bx[u] = io.xe[rr * 8 + xcol] * xmask;
+                static_for<0, NBJ>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    t.by[u][c] = y1[rr * LD + ycol[c]] * ymask[c];
+                });
+            }
+        }
+    };
+    Batch cur, nxt;
+    if (s0 < s1) load(s0, cur);
+    for (int sb = s0; sb < s1; sb += U) {
+        if (sb + U < s1) load(sb + U, nxt);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (FIRST) acch0 = mfma(cur.ah[u], cur.bh0[u], acch0);
+            if constexpr (SECOND) acch1 = mfma(cur.ah[u], cur.bh1[u], acch1);
+            if constexpr (ROWS) {
+                acc1 = mfma(cur.a1[u], cur.bx[u], acc1);
+                static_for<0, NBJ>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    acc2[c] = mfma(cur.a2[u], cur.by[u][c], acc2[c]);
+                });
+            }
+        }
+        cur = nxt;
+    }
+    if constexpr (ROWS) {
+        static_for<0, NBJ>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            store_block(acc2[c], out + L::g2 + (size_t)32 * w * L::LDO + 32 * c, L::LDO, lane);
+        });
+        store_block(acc1, out + L::g1 + (size_t)32 * w * 32, 32, lane);
+    }
+    if constexpr (FIRST) store_block(acch0, out + L::gh + 32 * w, L::LDO, lane);
+    if constexpr (SECOND) store_block(acch1, out + L::gh + 32 * (w + 4), L::LDO, lane);
+}
+
+template <int H>
+__global__ __launch_bounds__(PPO_THREADS) void ppo_products_kernel(MarlPpoIO io, int B, float* __restrict__ partial) {
+    using L = ProductLayout<H>;
+    constexpr int NBO = L::NBO, NBJ = L::NBJ;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: scalar branches
+    const bool critic = wave >= 4;
+    const int w = wave & 3;
+    const int steps = (B + 1) / 2;
+    const int per = (steps + gridDim.x - 1) / gridDim.x;
+    const int s0 = blockIdx.x * per, s1 = min(steps, s0 + per);
+    float* out = partial + (size_t)blockIdx.x * L::total + (critic ? L::half : 0);
+    const bool rows = w < NBO, first = w < NBJ, second = w + 4 < NBJ;
+    if (rows && second) products_body<H, true, true, true>(io, B, out, w, critic, lane, s0, s1);
+    else if (rows) products_body<H, true, true, false>(io, B, out, w, critic, lane, s0, s1);      // NBO <= NBJ: rows imply first
+    else if (first) products_body<H, false, true, false>(io, B, out, w, critic, lane, s0, s1);
+}
+
 int g_ppo_cus = 0;
 
 }  // namespace
@@ -460,6 +583,34 @@ static int ppo_cus() {
 }
 
 int32_t marl_ppo_ln_rows(void) { return ppo_cus() * PPO_WAVES; }
+
+int32_t marl_ppo_partial_rows(void) { return ppo_cus(); }
+
+size_t marl_ppo_partial_floats(int32_t hidden) {
+    switch (hidden) {
+        case 64: return ProductLayout<64>::total;
+        case 128: return ProductLayout<128>::total;
+        default: return 0;
+    }
+}
+
+int marl_ppo_products(int32_t B, int32_t hidden, const MarlPpoIO* io, float* partial, void* stream) {
+    if (io == nullptr || partial == nullptr || B < 1) return MARL_EINVAL;
+    if (hidden != 64 && hidden != 128) return MARL_EUNSUPPORTED;
+    if (io->xe == nullptr || io->y1e == nullptr || io->y2e == nullptr || io->dz1 == nullptr || io->dz2 == nullptr ||
+        io->dh == nullptr || io->cy1e == nullptr || io->cy2e == nullptr || io->cdz1 == nullptr || io->cdz2 == nullptr ||
+        io->dv == nullptr)
+        return MARL_EINVAL;
+    const int grid = ppo_cus();                 // every workgroup writes its partial blocks (zeros if it has no rows)
+    if (hidden == 64)
+        hipLaunchKernelGGL(ppo_products_kernel<64>, dim3(grid), dim3(PPO_THREADS), 0, (hipStream_t)stream, *io, (int)B, partial);
+    else
+        hipLaunchKernelGGL(ppo_products_kernel<128>, dim3(grid), dim3(PPO_THREADS), 0, (hipStream_t)stream, *io, (int)B, partial);
+    const hipError_t err = hipGetLastError();
+    if (err == hipSuccess) return MARL_OK;
+    marl_note_hip_error((int)err);
+    return MARL_EHIP;
+}
 
 int marl_ppo_rows(int32_t B, int32_t hidden, const MarlPpoIO* io, void* stream) {
     if (io == nullptr || B < 1) return MARL_EINVAL;
