@@ -446,8 +446,9 @@ class PPOAgent:
         self._graph_update = bool(graph_update) and self.device.type == "cuda" and batch_size <= self.GRAPH_MAX_BATCH
         on_gpu = self.device.type == "cuda"
         mk_lr = (lambda v: torch.tensor(float(v), device=self.device)) if on_gpu else float
-        self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=mk_lr(lr_actor), capturable=on_gpu)
-        self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr=mk_lr(lr_critic), capturable=on_gpu)
+        # fused: one launch per optimiser step instead of a dozen (same arithmetic, same state dict)
+        self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=mk_lr(lr_actor), capturable=on_gpu, fused=on_gpu)
+        self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr=mk_lr(lr_critic), capturable=on_gpu, fused=on_gpu)
         self._c2_t = torch.tensor(float(c2), device=self.device)
         self._step_graph, self._step_static, self._eager_steps = None, None, 0
         self._sync = FlatGradSync([self.actor, self.critic])
