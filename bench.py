@@ -250,7 +250,9 @@ def main():
                  "rollout_length": ROLLOUT_T, "ppo_epochs": tr.agent.n_epochs,
                  "minibatch": tr.agent.batch_size,
                  "timed_region": "rollouts (policy inference + step + buffer writes, replayed HIP graph) and PPO updates "
-                                 "(GAE kernel, 10 epochs x 32 minibatches unless the KL test stops earlier)"}
+                                 "(GAE kernel, 10 epochs x 32 minibatches unless the KL test stops earlier; a minibatch step = marl_ppo_rows + "
+                                 "marl_ppo_products + gradient all-reduce + clip + Adam)",
+                 "fused_update": bool(tr.agent.fused_update)}
         env_for_stage = solo
     else:
         shards = args.shards if args.shards is not None else {3: 3, 2: 2}.get(args.config, 1)
