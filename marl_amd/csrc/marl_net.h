@@ -103,11 +103,35 @@ __device__ __forceinline__ void first_layer(const float* __restrict__ f1, int la
 }
 
 // Layer 2: acc[bo] (initialised with the bias) += W2 . y, y = the lane's accumulators of the layer before.
-template <int NB>
+// PREFETCH = false: a group's weights are read right before its matrix instructions (4 NB registers less; the
+// other wave of the SIMD covers the LDS latency).
+template <int NB, bool PREFETCH = true>
 __device__ __forceinline__ void hidden_layer(const float* __restrict__ f2, int lane, const floatx16 (&y)[NB], floatx16 (&acc)[NB]) {
     constexpr int NS = NB * 16;
-    float4 w[NB], wn[NB];
     const float* base = f2 + opaque(lane * 4);
+    if constexpr (!PREFETCH) {
+        static_for<0, NS / 4>([&](auto ss) {
+            constexpr int s4 = decltype(ss)::value;
+            float4 w[NB];
+            static_for<0, NB>([&](auto bb) {
+                constexpr int bo = decltype(bb)::value;
+                w[bo] = *reinterpret_cast<const float4*>(base + (bo * (NS / 4) + s4) * 256);
+            });
+            static_for<0, 4>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                constexpr int s = 4 * s4 + q;
+                const float yk = y[s / 16][s % 16];
+                static_for<0, NB>([&](auto bb) {
+                    constexpr int bo = decltype(bb)::value;
+                    const float wk = q == 0 ? w[bo].x : (q == 1 ? w[bo].y : (q == 2 ? w[bo].z : w[bo].w));
+                    acc[bo] = mfma(wk, yk, acc[bo]);
+                });
+            });
+            LDS_FENCE();
+        });
+        return;
+    }
+    float4 w[NB], wn[NB];
     static_for<0, NB>([&](auto bb) {
         constexpr int bo = decltype(bb)::value;
         w[bo] = *reinterpret_cast<const float4*>(base + (bo * (NS / 4)) * 256);

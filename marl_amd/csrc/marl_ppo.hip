@@ -206,14 +206,17 @@ __device__ __forceinline__ float wave_total(float v) {
     return v;
 }
 
-template <int H>
-__global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int B, int actor_blocks) {
+// ACTOR selects the network: one launch each (two bodies in one kernel are more code than the instruction cache
+// of a CU pair holds, and the workgroups of the lighter network would idle at the end).
+template <int H, bool ACTOR>
+__global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int B) {
     using P = TrainPack<H>;
     constexpr int NB = P::NB, NS = P::NS, LD = H + 4;
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const int hl = lane >> 5, j = lane & 31;
-    const bool actor = (int)blockIdx.x < actor_blocks;
+    constexpr bool actor = ACTOR;
+    const int actor_blocks = ACTOR ? (int)gridDim.x : 0;
     {
         const float4* src = reinterpret_cast<const float4*>(io.weights + (actor ? 0 : P::c_f1));
         const int n4 = (actor ? P::a_end : P::total - P::c_f1) / 4;
@@ -223,28 +226,44 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int
     __syncthreads();
     const int tiles = (B + 31) / 32;
     const float inv_b = 1.0f / (float)B;
-    if (actor) {
+    if constexpr (ACTOR) {
         float s_loss = 0.0f, s_ent = 0.0f, s_clip = 0.0f, s_kl = 0.0f;
         float acc_e1[NB] = {}, acc_g1[NB] = {}, acc_e2[NB] = {}, acc_g2[NB] = {};      // LayerNorm parameter gradients
-        for (int tile = blockIdx.x * PPO_WAVES + wave; tile < tiles; tile += actor_blocks * PPO_WAVES) {
+        // The row's inputs are loaded one tile ahead: loads issued before a tile's stores are older than them, so waiting
+        // for the loads does not wait for the stores (one counter covers both, in order).
+        struct RowIn { float o0, o1, o2, o3, o4, a0, a1, a2, old, adv; };
+        auto load_row = [&](int tile) {
             const int p = tile * 32 + j;
-            const bool valid = PPO_STORE_ROWS && p < B;
-            const int pp = valid ? p : B - 1;
+            const int pp = p < B ? p : B - 1;
             const size_t r = io.index ? (size_t)io.index[pp] : (size_t)pp;
             const float* o = io.obs + r * OBS;
-            const float o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3], o4 = o[4];
+            const float* a = io.actions + r * 3;
+            return RowIn{o[0], o[1], o[2], o[3], o[4], a[0], a[1], a[2], io.old_log_probs[r], io.advantages[r]};
+        };
+        const int tile0 = blockIdx.x * PPO_WAVES + wave, tstride = actor_blocks * PPO_WAVES;
+        RowIn nxt = load_row(tile0 < tiles ? tile0 : 0);
+        for (int tile = tile0; tile < tiles; tile += tstride) {
+            const int p = tile * 32 + j;
+            const bool valid = PPO_STORE_ROWS && p < B;
+            const RowIn in = nxt;
+            if (tile + tstride < tiles) nxt = load_row(tile + tstride);
+            const float o0 = in.o0, o1 = in.o1, o2 = in.o2, o3 = in.o3, o4 = in.o4;
             const float x0 = hl ? o1 : o0, x1 = hl ? o3 : o2, x2 = hl ? 1.0f : o4;
             if (valid) {                                     // [obs | 1 | 0 0], shared with the critic's products
                 float4* xe = reinterpret_cast<float4*>(io.xe + (size_t)p * 8);
                 xe[hl] = hl ? make_float4(o4, 1.0f, 0.0f, 0.0f) : make_float4(o0, o1, o2, o3);
             }
-            floatx16 n1[NB], n2[NB], y[NB];
-            first_layer<NB>(lds + P::a_f1, lane, x0, x1, x2, n1);
-            const float rstd1 = normalise<NB>(n1);
-            affine_relu_store<NB>(n1, lds + P::a_g1, lds + P::a_e1, hl, y, io.y1e + (size_t)p * LD, valid);
+            floatx16 n2[NB], y[NB];
+            {   // layer 1; its normalised pre-activations are worked out again where the backward pass needs them
+                // (12 matrix instructions) instead of being carried through the whole tile in 64 registers
+                floatx16 n1[NB];
+                first_layer<NB>(lds + P::a_f1, lane, x0, x1, x2, n1);
+                normalise<NB>(n1);
+                affine_relu_store<NB>(n1, lds + P::a_g1, lds + P::a_e1, hl, y, io.y1e + (size_t)p * LD, valid);
+            }
             if (valid && hl == 0) *reinterpret_cast<float4*>(io.y1e + (size_t)p * LD + H) = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
             unit_vector<NB>(lds + P::a_b2, hl, n2);
-            hidden_layer<NB>(lds + P::a_f2, lane, y, n2);
+            hidden_layer<NB, false>(lds + P::a_f2, lane, y, n2);
             const float rstd2 = normalise<NB>(n2);
             affine_relu_store<NB>(n2, lds + P::a_g2, lds + P::a_e2, hl, y, io.y2e + (size_t)p * LD, valid);
             if (valid && hl == 0) *reinterpret_cast<float4*>(io.y2e + (size_t)p * LD + H) = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
@@ -274,10 +293,9 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int
             for (int q = 0; q < 4; ++q) lg[q] = hl ? mine[q] : other[q];
             // evaluate_actions (actor.py:204-247) and the losses of ppo_agent.py:296-316; every lane of the row's pair
             // computes the same values
-            const float* act = io.actions + r * 3;
             const float vlim = 2.0f * io.v_max;
-            const float a0 = fminf(fmaxf(act[0], -vlim), vlim), a1 = fminf(fmaxf(act[1], -vlim), vlim);
-            int band = (int)act[2];
+            const float a0 = fminf(fmaxf(in.a0, -vlim), vlim), a1 = fminf(fmaxf(in.a1, -vlim), vlim);
+            int band = (int)in.a2;
             band = band < 0 ? 0 : (band > 3 ? 3 : band);
             const float ls0 = fminf(fmaxf(rl0, io.log_std_min), io.log_std_max), ls1 = fminf(fmaxf(rl1, io.log_std_min), io.log_std_max);
             const bool in0 = rl0 >= io.log_std_min && rl0 <= io.log_std_max, in1 = rl1 >= io.log_std_min && rl1 <= io.log_std_max;
@@ -294,8 +312,8 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int
             const float HALF_LOG_2PI = 0.91893853320467274f;
             const float lp = (-0.5f * z0 * z0 - ls0 - HALF_LOG_2PI) + (-0.5f * z1 * z1 - ls1 - HALF_LOG_2PI) + lpk[band];
             const float ent = (0.5f + HALF_LOG_2PI + ls0) + (0.5f + HALF_LOG_2PI + ls1) + hcat;
-            const float dlt = lp - io.old_log_probs[r];
-            const float ratio = expf(dlt), adv = io.advantages[r];
+            const float dlt = lp - in.old;
+            const float ratio = expf(dlt), adv = in.adv;
             const float lo = 1.0f - io.clip_eps, hi = 1.0f + io.clip_eps;
             const float s1 = ratio * adv, s2 = fminf(fmaxf(ratio, lo), hi) * adv;
             const bool inside = ratio >= lo && ratio <= hi;
@@ -337,8 +355,10 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int
             store_units<NB>(d, hl, io.dz2 + (size_t)p * H, valid);
             // dL/dy1 = W2^T dz2
             static_for<0, NB>([&](auto bb) { y[decltype(bb)::value] = floatx16{0}; });
-            hidden_layer<NB>(lds + P::a_f2T, lane, d, y);
-            layer_norm_backward<NB>(y, n1, rstd1, lds + P::a_g1, lds + P::a_e1, hl, j, acc_e1, acc_g1);
+            hidden_layer<NB, false>(lds + P::a_f2T, lane, d, y);
+            first_layer<NB>(lds + P::a_f1, lane, x0, x1, x2, n2);          // n2 is free again: layer 1's pre-activations
+            const float rstd1 = normalise<NB>(n2);
+            layer_norm_backward<NB>(y, n2, rstd1, lds + P::a_g1, lds + P::a_e1, hl, j, acc_e1, acc_g1);
             store_units<NB>(y, hl, io.dz1 + (size_t)p * H, valid);
         }
         if ((j & 16) == 0) {                  // this wave's sums over its tiles: (bias 1, weight 1, bias 2, weight 2) x H
@@ -357,7 +377,7 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int
             atomicAdd(io.stats + 4, (double)s_kl);
         }
     } else {
-        const int nblocks = gridDim.x - actor_blocks;
+        const int nblocks = gridDim.x;
         const float* cf1 = lds;
         const float* cf2 = lds + (P::c_f2 - P::c_f1);
         const float* cb2 = lds + (P::c_b2 - P::c_f1);
@@ -423,6 +443,7 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int
             floatx16 dy[NB];
             static_for<0, NB>([&](auto bb) { dy[decltype(bb)::value] = floatx16{0}; });
             hidden_layer<NB>(cf2T, lane, y2, dy);
+            first_layer<NB>(cf1, lane, x0, x1, x2, y1);                     // layer 1's pre-activations again, for the ReLU mask
             static_for<0, NB>([&](auto bb) { static_for<0, 16>([&](auto vv) {
                 constexpr int b = decltype(bb)::value, q = decltype(vv)::value;
                 dy[b][q] = y1[b][q] > 0.0f ? dy[b][q] : 0.0f; }); });
@@ -486,7 +507,8 @@ __device__ __forceinline__ void products_body(const MarlPpoIO& io, int B, float*
     const int hc0 = 32 * w + i, hc1 = 32 * (w + 4) + i;      // this wave's columns of the head product
     const int hcol0 = hc0 < LD ? hc0 : LD - 1, hcol1 = hc1 < LD ? hc1 : LD - 1;
     const float hm0 = hc0 < LD ? 1.0f : 0.0f, hm1 = hc1 < LD ? 1.0f : 0.0f;
-    // Software pipeline: the loads of batch n + 1 (U steps) are in flight while the matrix instructions of batch n run.
+    // Software pipeline: the loads of batch n + 1 (U steps) are in flight while the matrix instructions of batch n run
+    // (two batches ahead does not fit the registers: 73 spills, 1.2 ms instead of 0.45).
     struct Batch { float ah[U], bh0[U], bh1[U], a2[U], a1[U], bx[U], by[U][NBJ]; };
     auto load = [&](int sb, Batch& t) {
 #pragma unroll
@@ -622,31 +644,30 @@ int marl_ppo_rows(int32_t B, int32_t hidden, const MarlPpoIO* io, void* stream) 
         io->cy2e == nullptr || io->cdz1 == nullptr || io->cdz2 == nullptr || io->dv == nullptr)
         return MARL_EINVAL;
     const int tiles = (B + 31) / 32;
-    int grid = ppo_cus();
-    if (2 * tiles < grid * PPO_WAVES) grid = (2 * tiles + PPO_WAVES - 1) / PPO_WAVES;
-    if (grid < 2) grid = 2;
-    // matrix instructions per tile: actor 3 layers forward + heads^T + W2^T, critic 2 layers forward + W2^T
-    const double wa = hidden / 32 * 3 + hidden / 32 * hidden / 2 * 2 + hidden / 2 + hidden / 32 * 4;
-    const double wc = hidden / 32 * 3 + hidden / 32 * hidden / 2 * 2;
-    int actor_blocks = (int)(grid * wa / (wa + wc) + 0.5);
-    if (actor_blocks < 1) actor_blocks = 1;
-    if (actor_blocks > grid - 1) actor_blocks = grid - 1;
+    int grid = ppo_cus();                                  // one workgroup per CU; fewer for a small minibatch
+    if (tiles < grid * PPO_WAVES) grid = (tiles + PPO_WAVES - 1) / PPO_WAVES;
     // waves that do not run leave their rows of the partial sums at zero
     hipError_t err = hipMemsetAsync(io->ln_sums, 0, (size_t)marl_ppo_ln_rows() * 4 * hidden * sizeof(float), (hipStream_t)stream);
-#define MARL_LAUNCH_PPO(HH)                                                                                          \
+#define MARL_LAUNCH_PPO(HH, ACTOR, FLOATS)                                                                           \
     do {                                                                                                              \
         static bool attr_set = false;                                                                                 \
-        const size_t lds_bytes = (size_t)TrainPack<HH>::lds_floats * sizeof(float);                                   \
-        if (!attr_set) {                                                                                              \
-            err = hipFuncSetAttribute((const void*)ppo_rows_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                      (int)lds_bytes);                                                                \
+        const size_t lds_bytes = (size_t)(FLOATS) * sizeof(float);                                                    \
+        if (err == hipSuccess && !attr_set) {                                                                         \
+            err = hipFuncSetAttribute((const void*)ppo_rows_kernel<HH, ACTOR>,                                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                    \
             attr_set = err == hipSuccess;                                                                             \
         }                                                                                                             \
         if (err == hipSuccess)                                                                                        \
-            hipLaunchKernelGGL(ppo_rows_kernel<HH>, dim3(grid), dim3(PPO_THREADS), lds_bytes, (hipStream_t)stream, *io, \
-                               (int)B, actor_blocks);                                                                 \
+            hipLaunchKernelGGL((ppo_rows_kernel<HH, ACTOR>), dim3(grid), dim3(PPO_THREADS), lds_bytes,               \
+                               (hipStream_t)stream, *io, (int)B);                                                     \
     } while (0)
-    if (hidden == 64) MARL_LAUNCH_PPO(64); else MARL_LAUNCH_PPO(128);
+    if (hidden == 64) {
+        MARL_LAUNCH_PPO(64, true, TrainPack<64>::a_end);
+        MARL_LAUNCH_PPO(64, false, TrainPack<64>::total - TrainPack<64>::c_f1);
+    } else {
+        MARL_LAUNCH_PPO(128, true, TrainPack<128>::a_end);
+        MARL_LAUNCH_PPO(128, false, TrainPack<128>::total - TrainPack<128>::c_f1);
+    }
 #undef MARL_LAUNCH_PPO
     if (err == hipSuccess) err = hipGetLastError();
     if (err == hipSuccess) return MARL_OK;

@@ -3,7 +3,7 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/ppmc
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d gpurun_out/ppmc -o r -- python3 tools/ppo_rows_bench.py > gpurun_out/ppmc.log 2>&1 || { tail -5 gpurun_out/ppmc.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc ${PPO_PMC:-SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS} --output-format csv -d gpurun_out/ppmc -o r -- python3 tools/ppo_rows_bench.py > gpurun_out/ppmc.log 2>&1 || { tail -5 gpurun_out/ppmc.log; exit 1; }
 f=$(find gpurun_out/ppmc -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections
