@@ -208,8 +208,11 @@ __device__ __forceinline__ float wave_total(float v) {
 
 // ACTOR selects the network: one launch each (two bodies in one kernel are more code than the instruction cache
 // of a CU pair holds, and the workgroups of the lighter network would idle at the end).
+// The critic's tile needs 170 registers: three waves per SIMD (768 threads), where the actor's fits two.
+template <bool ACTOR> constexpr int ROWS_THREADS = ACTOR ? PPO_THREADS : 768;
 template <int H, bool ACTOR>
-__global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int B) {
+__global__ __launch_bounds__(ROWS_THREADS<ACTOR>) void ppo_rows_kernel(MarlPpoIO io, int B) {
+    constexpr int THREADS = ROWS_THREADS<ACTOR>, WAVES = THREADS / WAVE;
     using P = TrainPack<H>;
     constexpr int NB = P::NB, NS = P::NS, LD = H + 4;
     extern __shared__ __align__(16) float lds[];
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int
         const float4* src = reinterpret_cast<const float4*>(io.weights + (actor ? 0 : P::c_f1));
         const int n4 = (actor ? P::a_end : P::total - P::c_f1) / 4;
         float4* dst = reinterpret_cast<float4*>(lds);
-        for (int i = tid; i < n4; i += PPO_THREADS) dst[i] = src[i];
+        for (int i = tid; i < n4; i += THREADS) dst[i] = src[i];
     }
     __syncthreads();
     const int tiles = (B + 31) / 32;
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int
             const float* a = io.actions + r * 3;
             return RowIn{o[0], o[1], o[2], o[3], o[4], a[0], a[1], a[2], io.old_log_probs[r], io.advantages[r]};
         };
-        const int tile0 = blockIdx.x * PPO_WAVES + wave, tstride = actor_blocks * PPO_WAVES;
+        const int tile0 = blockIdx.x * WAVES + wave, tstride = actor_blocks * WAVES;
         RowIn nxt = load_row(tile0 < tiles ? tile0 : 0);
         for (int tile = tile0; tile < tiles; tile += tstride) {
             const int p = tile * 32 + j;
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int
             store_units<NB>(y, hl, io.dz1 + (size_t)p * H, valid);
         }
         if ((j & 16) == 0) {                  // this wave's sums over its tiles: (bias 1, weight 1, bias 2, weight 2) x H
-            float* out = io.ln_sums + (size_t)(blockIdx.x * PPO_WAVES + wave) * 4 * H;
+            float* out = io.ln_sums + (size_t)(blockIdx.x * WAVES + wave) * 4 * H;
             static_for<0, NB>([&](auto bb) {
                 constexpr int b = decltype(bb)::value;
                 const int u = scattered_unit(b, j, hl);
@@ -385,13 +388,22 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int
         const float cb3 = lds[P::c_b3 - P::c_f1];
         const float* cf2T = lds + (P::c_f2T - P::c_f1);
         float s_vloss = 0.0f;
-        for (int tile = ((int)blockIdx.x - actor_blocks) * PPO_WAVES + wave; tile < tiles; tile += nblocks * PPO_WAVES) {
+        struct RowIn { float x0, x1, x2, ret; };                 // loaded one tile ahead, as in the actor's pass
+        auto load_row = [&](int tile) {
             const int p = tile * 32 + j;
-            const bool valid = PPO_STORE_ROWS && p < B;
-            const int pp = valid ? p : B - 1;
+            const int pp = p < B ? p : B - 1;
             const size_t r = io.index ? (size_t)io.index[pp] : (size_t)pp;
             const float* o = io.obs + r * OBS;
-            const float x0 = o[hl], x1 = o[2 + hl], x2 = hl ? 1.0f : o[4];
+            return RowIn{o[hl], o[2 + hl], hl ? 1.0f : o[4], io.returns[r]};
+        };
+        const int tile0 = (int)blockIdx.x * WAVES + wave, tstride = nblocks * WAVES;
+        RowIn nxt = load_row(tile0 < tiles ? tile0 : 0);
+        for (int tile = tile0; tile < tiles; tile += tstride) {
+            const int p = tile * 32 + j;
+            const bool valid = PPO_STORE_ROWS && p < B;
+            const RowIn in = nxt;
+            if (tile + tstride < tiles) nxt = load_row(tile + tstride);
+            const float x0 = in.x0, x1 = in.x1, x2 = in.x2;
             floatx16 y1[NB], y2[NB];
             first_layer<NB>(cf1, lane, x0, x1, x2, y1);
             static_for<0, NB>([&](auto bb) { static_for<0, 16>([&](auto vv) {
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_rows_kernel(MarlPpoIO io, int
             });
             v += __shfl_xor(v, 32);
             v += cb3;
-            const float err = v - io.returns[r];
+            const float err = v - in.ret;
             const float dv = valid ? 2.0f * io.c1 * err * inv_b : 0.0f;                 // d(c1 mean (v - ret)^2)/dv
             if (valid && hl == 0) {
                 io.dv[p] = dv;
@@ -644,8 +656,7 @@ int marl_ppo_rows(int32_t B, int32_t hidden, const MarlPpoIO* io, void* stream) 
         io->cy2e == nullptr || io->cdz1 == nullptr || io->cdz2 == nullptr || io->dv == nullptr)
         return MARL_EINVAL;
     const int tiles = (B + 31) / 32;
-    int grid = ppo_cus();                                  // one workgroup per CU; fewer for a small minibatch
-    if (tiles < grid * PPO_WAVES) grid = (tiles + PPO_WAVES - 1) / PPO_WAVES;
+    const int cus = ppo_cus();                             // one workgroup per CU; fewer for a small minibatch
     // waves that do not run leave their rows of the partial sums at zero
     hipError_t err = hipMemsetAsync(io->ln_sums, 0, (size_t)marl_ppo_ln_rows() * 4 * hidden * sizeof(float), (hipStream_t)stream);
 #define MARL_LAUNCH_PPO(HH, ACTOR, FLOATS)                                                                           \
@@ -657,8 +668,10 @@ int marl_ppo_rows(int32_t B, int32_t hidden, const MarlPpoIO* io, void* stream) 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                    \
             attr_set = err == hipSuccess;                                                                             \
         }                                                                                                             \
+        const int waves = ROWS_THREADS<ACTOR> / WAVE;                                                                 \
+        const int grid = tiles < cus * waves ? (tiles + waves - 1) / waves : cus;                                     \
         if (err == hipSuccess)                                                                                        \
-            hipLaunchKernelGGL((ppo_rows_kernel<HH, ACTOR>), dim3(grid), dim3(PPO_THREADS), lds_bytes,               \
+            hipLaunchKernelGGL((ppo_rows_kernel<HH, ACTOR>), dim3(grid), dim3(ROWS_THREADS<ACTOR>), lds_bytes,       \
                                (hipStream_t)stream, *io, (int)B);                                                     \
     } while (0)
     if (hidden == 64) {
