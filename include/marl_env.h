@@ -314,19 +314,31 @@ size_t marl_policy_weight_count(int32_t hidden);
 int marl_policy_act(int32_t E, int32_t M, int32_t hidden, float v_max, float log_std_min, float log_std_max,
                     const MarlPolicyIO *io, void *stream);
 
-/* ---- PPO minibatch step: the per-row pass -------------------------------------------------------------
- * PPOAgent.update (agents/ppo_agent.py:296-331) for one minibatch, up to the sums over rows: forward of actor
- * (Actor.evaluate_actions, agents/actor.py:204-247) and critic (agents/critic.py:124-134, applied to the row's
- * observation as the reference's update does), the losses
+/* ---- PPO minibatch step ----------------------------------------------------------------------------------
+ * PPOAgent.update (agents/ppo_agent.py:296-331) for one minibatch, up to the optimiser.
+ *
+ * marl_ppo_rows, the per-row pass (one launch per network): forward of actor (Actor.evaluate_actions,
+ * agents/actor.py:204-247) and critic (agents/critic.py:124-134, applied to the row's observation as the reference's
+ * update does), the losses
  *     actor  = mean(-min(ratio A, clip(ratio, 1 +- eps) A)) - c2 mean(entropy),   critic = c1 mean((V - R)^2),
- * and the backward pass down to every layer's pre-activation, one minibatch row per lane on the matrix cores.
- * The gradient of a parameter is then a product of two of the [B][.] matrices written here (the 1/B of the means
- * is already applied):
- *   actor   trunk.0 [W | b] = dz1^T xe[:, :6]      trunk.3 [W | b] = dz2^T y1e[:, :H+1]
- *           LayerNorm weights and biases: ln_sums summed over its first dimension (summed in the kernel: a
- *           reduce-scatter over the 32 rows of a tile, then per-wave running sums)
- *           heads   [W | b] = dh^T y2e[:, :H+1]          (rows: mu 0-1, log_std 2-3, band 4-7)
- *   critic  network.0 [W | b] = cdz1^T xe[:, :6]   network.2 [W | b] = cdz2^T cy1e[:, :H+1]   network.4 [W | b] = dv^T cy2e[:, :H+1]
+ * and the backward pass down to every layer's pre-activation, one minibatch row per lane on the matrix cores (the
+ * 1/B of the means is applied).  It writes the row matrices whose products are the weight gradients and sums the
+ * per-unit gradients (LayerNorm parameters, biases) itself.
+ *
+ * Row matrices with H columns are stored TILE-MAJOR: 32 rows at a time, each tile as H / 4 chunks of
+ * [32 rows][4 units]; element (row r, unit u) is float (r / 32) 32 H + (u / 4) 128 + (r % 32) 4 + u % 4.  All row arrays
+ * hold whole tiles: ceil(B / 32) 32 rows (rows beyond B carry zero gradients).
+ *
+ * marl_ppo_products, the sums over rows, one pass over those arrays (same io; only its out pointers are read):
+ * `partial` = [marl_ppo_partial_rows()][marl_ppo_partial_floats(hidden)], one slab per workgroup, to be summed over
+ * the first dimension.  A slab:
+ *   actor : dz2^T y1  [H][H]  = trunk.3.weight;   dz1^T xe [H][32]: columns 0..4 = trunk.0.weight, 5 = trunk.0.bias;
+ *           dh^T y2   [32][H]: rows 0-1 mu_head, 2-3 log_std_head, 4-7 band_head;
+ *           dz2^T xe  [H][32]: column 5 = trunk.3.bias;   dh^T xe [32][32]: column 5 of rows 0..7 = the head biases
+ *   critic: cdz2^T cy1 [H][H] = network.2.weight; cdz1^T xe [H][32] = network.0 (weight | bias); dv^T cy2 [32][H]: row 0 =
+ *           network.4.weight; cdz2^T xe [H][32]: column 5 = network.2.bias; dv^T xe [32][32]: row 0 column 5 = network.4.bias
+ * The LayerNorm gradients are actor_sums summed over its first dimension.
+ *
  * `stats` (float64 [5], added to): sums over the rows of the actor loss term, c1 (V - R)^2, the entropy, the
  * clip indicator |ratio - 1| > eps and the KL estimate (ratio - 1) - log ratio (ppo_agent.py:333-345).
  * hidden = 64 or 128; weights: marl_ppo_weight_count(hidden) floats, the layout of marl_policy_act's buffer with
@@ -343,29 +355,22 @@ typedef struct MarlPpoIO {
     const float *advantages;     /* [R] */
     const float *returns;        /* [R] */
     const int64_t *index;        /* [B] rows of the minibatch; NULL = rows 0 .. B-1 */
-    float *xe;                   /* [B][8]    out: obs, 1, 0, 0 */
-    float *y1e, *y2e;            /* [B][H+4]  out: actor activations after each LayerNorm + ReLU, then 1, 0, 0, 0 */
-    float *dz1, *dz2;            /* [B][H]    out: actor dL/dz per layer */
-    float *ln_sums;              /* [marl_ppo_ln_rows()][4][H] out: per wave, the sums over its rows of (dL/d(LayerNorm 1
-                                    output), the same times the normalised z, and both for LayerNorm 2); the sum over the
-                                    first dimension is the gradient of (trunk.1.bias, trunk.1.weight, trunk.4.bias, trunk.4.weight) */
-    float *dh;                   /* [B][8]    out: dL/d(head outputs) */
-    float *cy1e, *cy2e;          /* [B][H+4]  out: critic activations, then 1, 0, 0, 0 */
-    float *cdz1, *cdz2;          /* [B][H]    out: critic dL/dz per layer */
-    float *dv;                   /* [B]       out: dL/dV */
+    float *xe;                   /* [rows][8]  out, row-major: obs, 1, 0, 0 */
+    float *y1e, *y2e;            /* [rows][H]  out, tile-major: actor activations after each LayerNorm + ReLU */
+    float *dz1, *dz2;            /* [rows][H]  out, tile-major: actor dL/dz per layer */
+    float *actor_sums;           /* [marl_ppo_sum_rows()][4 H] out, one row per wave: sums over its minibatch rows of
+                                    dL/d(LayerNorm 1 output) (= trunk.1.bias), the same times the normalised z (trunk.1.weight),
+                                    and both for LayerNorm 2 (trunk.4.bias, trunk.4.weight) */
+    float *dh;                   /* [rows][8]  out, row-major: dL/d(head outputs) */
+    float *cy1e, *cy2e;          /* [rows][H]  out, tile-major: critic activations */
+    float *cdz1, *cdz2;          /* [rows][H]  out, tile-major: critic dL/dz per layer */
+    float *dv;                   /* [rows]     out: dL/dV */
     double *stats;               /* [5] in/out, optional */
     float clip_eps, c1, c2, v_max, log_std_min, log_std_max;
 } MarlPpoIO;
 size_t marl_ppo_weight_count(int32_t hidden);
-int32_t marl_ppo_ln_rows(void);
+int32_t marl_ppo_sum_rows(void);
 int marl_ppo_rows(int32_t B, int32_t hidden, const MarlPpoIO *io, void *stream);
-
-/* The six row products above in one pass over what marl_ppo_rows wrote (same io; only its out pointers are read).
- * `partial`: [marl_ppo_partial_rows()][marl_ppo_partial_floats(hidden)] out, one slab per workgroup, to be summed
- * over the first dimension.  A slab, with LDO = 32 ceil((H + 4) / 32):
- *   actor : dz2^T y1e [H][LDO], dz1^T xe [H][32], dh^T y2e [32][LDO] (rows 0..7)
- *   critic: cdz2^T cy1e [H][LDO], cdz1^T xe [H][32], dv^T cy2e [32][LDO] (row 0)
- * Columns beyond H + 4 (and beyond 8 for xe) are zero. */
 int32_t marl_ppo_partial_rows(void);
 size_t marl_ppo_partial_floats(int32_t hidden);
 int marl_ppo_products(int32_t B, int32_t hidden, const MarlPpoIO *io, float *partial, void *stream);

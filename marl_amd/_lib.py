@@ -74,9 +74,9 @@ class MarlPolicyIO(C.Structure):
 class MarlPpoIO(C.Structure):
     _fields_ = [
         ("weights", _pf), ("obs", _pf), ("actions", _pf), ("old_log_probs", _pf), ("advantages", _pf), ("returns", _pf),
-        ("index", C.c_void_p), ("xe", _pf), ("y1e", _pf), ("y2e", _pf), ("dz1", _pf), ("dz2", _pf), ("ln_sums", _pf),
-        ("dh", _pf), ("cy1e", _pf), ("cy2e", _pf), ("cdz1", _pf),
-        ("cdz2", _pf), ("dv", _pf), ("stats", _pd),
+        ("index", C.c_void_p), ("xe", _pf), ("y1e", _pf), ("y2e", _pf), ("dz1", _pf), ("dz2", _pf), ("actor_sums", _pf),
+        ("dh", _pf), ("cy1e", _pf), ("cy2e", _pf), ("cdz1", _pf), ("cdz2", _pf), ("dv", _pf),
+        ("stats", _pd),
         ("clip_eps", C.c_float), ("c1", C.c_float), ("c2", C.c_float), ("v_max", C.c_float),
         ("log_std_min", C.c_float), ("log_std_max", C.c_float),
     ]
@@ -124,7 +124,7 @@ SYMBOLS = {
     "marl_policy_act": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
                                   C.POINTER(MarlPolicyIO), C.c_void_p]),
     "marl_ppo_weight_count": (C.c_size_t, [C.c_int32]),
-    "marl_ppo_ln_rows": (C.c_int32, []),
+    "marl_ppo_sum_rows": (C.c_int32, []),
     "marl_ppo_partial_rows": (C.c_int32, []),
     "marl_ppo_partial_floats": (C.c_size_t, [C.c_int32]),
     "marl_ppo_products": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(MarlPpoIO), _pf, C.c_void_p]),

@@ -596,11 +596,13 @@ class PPOAgent:
         z = self._fz
         if z["B"] < B:
             f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=self.device)
-            z.update(B=B, xe=f(B, 8), y1e=f(B, H + 4), y2e=f(B, H + 4), dz1=f(B, H), dz2=f(B, H), dh=f(B, 8),
-                     cy1e=f(B, H + 4), cy2e=f(B, H + 4), cdz1=f(B, H), cdz2=f(B, H), dv=f(B),
-                     ln_sums=f(_lib.load().marl_ppo_ln_rows(), 4, H))
+            lib = _lib.load()
+            R = 32 * ((B + 31) // 32)                    # the row arrays hold whole tiles of 32 rows
+            z.update(B=B, xe=f(R, 8), y1e=f(R, H), y2e=f(R, H), dz1=f(R, H), dz2=f(R, H), dh=f(R, 8),
+                     cy1e=f(R, H), cy2e=f(R, H), cdz1=f(R, H), cdz2=f(R, H), dv=f(R),
+                     actor_sums=f(lib.marl_ppo_sum_rows(), 4 * H))
             if "partial" not in z:
-                z["partial"] = f(_lib.load().marl_ppo_partial_rows(), _lib.load().marl_ppo_partial_floats(H))
+                z["partial"] = f(lib.marl_ppo_partial_rows(), lib.marl_ppo_partial_floats(H))
         return z
 
     def _fused_forward_backward(self, obs, actions, old_log_probs, advantages, returns, idx) -> torch.Tensor:
@@ -615,7 +617,7 @@ class PPOAgent:
         io.weights = weights.data_ptr()
         io.obs, io.actions, io.old_log_probs = obs.data_ptr(), actions.data_ptr(), old_log_probs.data_ptr()
         io.advantages, io.returns, io.index = advantages.data_ptr(), returns.data_ptr(), idx.data_ptr()
-        for k in ("xe", "y1e", "y2e", "dz1", "dz2", "ln_sums", "dh", "cy1e", "cy2e", "cdz1", "cdz2", "dv"):
+        for k in ("xe", "y1e", "y2e", "dz1", "dz2", "actor_sums", "dh", "cy1e", "cy2e", "cdz1", "cdz2", "dv"):
             setattr(io, k, z[k].data_ptr())
         io.stats = z["stats"].data_ptr()
         io.clip_eps, io.c1, io.c2, io.v_max = float(self.clip_eps), float(self.c1), float(self.c2), float(self.v_max)
@@ -629,26 +631,27 @@ class PPOAgent:
                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), "marl_ppo_products")
         # one slab per workgroup -> their sum; then cut into the six products (include/marl_env.h)
         tot = z["partial"].sum(0)
-        LDO = 32 * ((H + 4 + 31) // 32)
-        half = H * LDO + H * 32 + 32 * LDO
+        sizes = (H * H, H * 32, 32 * H, H * 32, 32 * 32)      # dz2^T y1, dz1^T xe, dh^T y2, dz2^T xe, dh^T xe
+        half = sum(sizes)
 
         def cut(base):
-            g2 = tot[base:base + H * LDO].view(H, LDO)
-            g1 = tot[base + H * LDO:base + H * LDO + H * 32].view(H, 32)
-            gh = tot[base + H * LDO + H * 32:base + half].view(32, LDO)
-            return g1, g2, gh
+            out, o = [], base
+            for n_, shape in zip(sizes, ((H, H), (H, 32), (32, H), (H, 32), (32, 32))):
+                out.append(tot[o:o + n_].view(shape))
+                o += n_
+            return out
 
-        g1, g2, gh = cut(0)
-        c1, c2, c3 = cut(half)
+        g2, g1, gh, gb, ghb = cut(0)
+        c2, c1, c3, cb, chb = cut(half)
         t, n = self.actor.trunk, self.critic.network
-        ln = z["ln_sums"].sum(0)                                          # (bias 1, weight 1, bias 2, weight 2) x H
-        grads = [(t[0].weight, g1[:, :5]), (t[0].bias, g1[:, 5]), (t[1].weight, ln[1]), (t[1].bias, ln[0]),
-                 (t[3].weight, g2[:, :H]), (t[3].bias, g2[:, H]), (t[4].weight, ln[3]), (t[4].bias, ln[2]),
-                 (self.actor.mu_head.weight, gh[0:2, :H]), (self.actor.mu_head.bias, gh[0:2, H]),
-                 (self.actor.log_std_head.weight, gh[2:4, :H]), (self.actor.log_std_head.bias, gh[2:4, H]),
-                 (self.actor.band_head.weight, gh[4:8, :H]), (self.actor.band_head.bias, gh[4:8, H]),
-                 (n[0].weight, c1[:, :5]), (n[0].bias, c1[:, 5]), (n[2].weight, c2[:, :H]), (n[2].bias, c2[:, H]),
-                 (n[4].weight, c3[0:1, :H]), (n[4].bias, c3[0:1, H])]
+        ln = z["actor_sums"].sum(0)              # LayerNorm 1 bias, weight, LayerNorm 2 bias, weight (H each)
+        grads = [(t[0].weight, g1[:, :5]), (t[0].bias, g1[:, 5]), (t[1].weight, ln[H:2 * H]), (t[1].bias, ln[:H]),
+                 (t[3].weight, g2), (t[3].bias, gb[:, 5]), (t[4].weight, ln[3 * H:4 * H]), (t[4].bias, ln[2 * H:3 * H]),
+                 (self.actor.mu_head.weight, gh[0:2]), (self.actor.mu_head.bias, ghb[0:2, 5]),
+                 (self.actor.log_std_head.weight, gh[2:4]), (self.actor.log_std_head.bias, ghb[2:4, 5]),
+                 (self.actor.band_head.weight, gh[4:8]), (self.actor.band_head.bias, ghb[4:8, 5]),
+                 (n[0].weight, c1[:, :5]), (n[0].bias, c1[:, 5]), (n[2].weight, c2), (n[2].bias, cb[:, 5]),
+                 (n[4].weight, c3[0:1]), (n[4].bias, chb[0:1, 5])]
         for p, g in grads:
             if p.grad is None:
                 p.grad = torch.empty_like(p)

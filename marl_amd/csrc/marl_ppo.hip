@@ -78,13 +78,18 @@ __device__ __forceinline__ float normalise(floatx16 (&x)[NB]) {
     return rstd;
 }
 
-// y = relu(n * g + e), written to row `out` (the lane's units, 16 bytes at a time) when `valid`.
+// Row matrices are written tile by tile (32 rows), each tile as H / 4 chunks of [32 rows][4 units]: element
+// (row r, unit u) sits at float (r / 32) 32 H + (u / 4) 128 + (r % 32) 4 + u % 4.  A lane owns four consecutive units
+// per register quad, so one store instruction of a wave covers two runs of 512 contiguous bytes (the row-major
+// form scatters it over 32 rows, 16 bytes each, which is what bounded the pass); the products kernel transposes
+// a tile through LDS.  `tile_out` = the tile's base + this lane's (4 j + 128 hl) floats.
+// y = relu(n * g + e), kept in y and written to the tile.
 template <int NB>
 __device__ __forceinline__ void affine_relu_store(const floatx16 (&n)[NB], const float* __restrict__ g, const float* __restrict__ e,
-                                                  int hl, floatx16 (&y)[NB], float* __restrict__ out, bool valid) {
+                                                  int hl, floatx16 (&y)[NB], float* __restrict__ tile_out) {
     const float* gb = g + opaque(4 * hl);
     const float* eb = e + opaque(4 * hl);
-    float* ob = out + 4 * hl;
+    float* ob = tile_out;
     asm volatile("" : "+v"(ob));
     static_for<0, NB>([&](auto bb) {
         constexpr int b = decltype(bb)::value;
@@ -99,23 +104,22 @@ __device__ __forceinline__ void affine_relu_store(const floatx16 (&n)[NB], const
             r.z = fmaxf(fmaf(n[b][4 * q + 2], gq.z, eq.z), 0.0f);
             r.w = fmaxf(fmaf(n[b][4 * q + 3], gq.w, eq.w), 0.0f);
             y[b][4 * q] = r.x; y[b][4 * q + 1] = r.y; y[b][4 * q + 2] = r.z; y[b][4 * q + 3] = r.w;
-            if (valid) *reinterpret_cast<float4*>(ob + u) = r;
+            *reinterpret_cast<float4*>(ob + (8 * b + 2 * q) * 128) = r;
             LDS_FENCE();
         });
     });
 }
 
-// The lane's units of a row, 16 bytes at a time.
+// The lane's units into the tile, 16 bytes at a time.
 template <int NB>
-__device__ __forceinline__ void store_units(const floatx16 (&x)[NB], int hl, float* __restrict__ out, bool valid) {
-    if (!valid) return;
-    float* ob = out + 4 * hl;
+__device__ __forceinline__ void store_units(const floatx16 (&x)[NB], float* __restrict__ tile_out) {
+    float* ob = tile_out;
     asm volatile("" : "+v"(ob));
     static_for<0, NB>([&](auto bb) {
         constexpr int b = decltype(bb)::value;
         static_for<0, 4>([&](auto qq) {
             constexpr int q = decltype(qq)::value;
-            *reinterpret_cast<float4*>(ob + 32 * b + 8 * q) =
+            *reinterpret_cast<float4*>(ob + (8 * b + 2 * q) * 128) =
                 make_float4(x[b][4 * q], x[b][4 * q + 1], x[b][4 * q + 2], x[b][4 * q + 3]);
         });
     });
@@ -145,11 +149,9 @@ __device__ __forceinline__ float reduce_scatter16(const float (&x)[16], int j) {
     float r = (b3 ? w[1] : w[0]) + dpp_f<0x128>(b3 ? w[0] : w[1]);                                           // row_ror:8 = lane ^ 8
     return r + swizzle_f<0x401F>(r);                                                                         // lane ^ 16
 }
-// The unit whose total reduce_scatter16 leaves in lane j of half hl, for accumulator block b.
-__device__ __forceinline__ int scattered_unit(int b, int j, int hl) {
-    const int v = 8 * (j & 1) + 4 * ((j >> 1) & 1) + 2 * ((j >> 2) & 1) + ((j >> 3) & 1);
-    return unit_of(b, v, hl);
-}
+// The value (0..15) whose total reduce_scatter16 leaves in lane j, and the unit that is for accumulator block b of half hl.
+__device__ __forceinline__ int scattered_index(int j) { return 8 * (j & 1) + 4 * ((j >> 1) & 1) + 2 * ((j >> 2) & 1) + ((j >> 3) & 1); }
+__device__ __forceinline__ int scattered_unit(int b, int j, int hl) { return unit_of(b, scattered_index(j), hl); }
 
 // Backward through y = relu(n g + e), n = LayerNorm-normalised z.  In: d = dL/dy; out: d = dL/dz.  The two
 // per-row terms of the LayerNorm parameter gradients, E = dL/d(n g + e) (summed over the rows: the gradient of
@@ -208,13 +210,14 @@ __device__ __forceinline__ float wave_total(float v) {
 
 // ACTOR selects the network: one launch each (two bodies in one kernel are more code than the instruction cache
 // of a CU pair holds, and the workgroups of the lighter network would idle at the end).
-// The critic's tile needs 170 registers: three waves per SIMD (768 threads), where the actor's fits two.
-template <bool ACTOR> constexpr int ROWS_THREADS = ACTOR ? PPO_THREADS : 768;
+// (Three waves per SIMD for the critic's pass, which would fit its registers, gain nothing: the pass is bound by
+// what a CU shares -- the matrix pipes and the store path -- not by latency.)
+template <bool ACTOR> constexpr int ROWS_THREADS = PPO_THREADS;
 template <int H, bool ACTOR>
 __global__ __launch_bounds__(ROWS_THREADS<ACTOR>) void ppo_rows_kernel(MarlPpoIO io, int B) {
     constexpr int THREADS = ROWS_THREADS<ACTOR>, WAVES = THREADS / WAVE;
     using P = TrainPack<H>;
-    constexpr int NB = P::NB, NS = P::NS, LD = H + 4;
+    constexpr int NB = P::NB, NS = P::NS;
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const int hl = lane >> 5, j = lane & 31;
@@ -252,24 +255,24 @@ __global__ __launch_bounds__(ROWS_THREADS<ACTOR>) void ppo_rows_kernel(MarlPpoIO
             if (tile + tstride < tiles) nxt = load_row(tile + tstride);
             const float o0 = in.o0, o1 = in.o1, o2 = in.o2, o3 = in.o3, o4 = in.o4;
             const float x0 = hl ? o1 : o0, x1 = hl ? o3 : o2, x2 = hl ? 1.0f : o4;
-            if (valid) {                                     // [obs | 1 | 0 0], shared with the critic's products
+            {   // [obs | 1 | 0 0], shared with the critic's products; every row of the tile is written (the arrays hold
+                // whole tiles; rows beyond the minibatch carry zero gradients below)
                 float4* xe = reinterpret_cast<float4*>(io.xe + (size_t)p * 8);
                 xe[hl] = hl ? make_float4(o4, 1.0f, 0.0f, 0.0f) : make_float4(o0, o1, o2, o3);
             }
+            const size_t tile_off = (size_t)tile * 32 * H + 4 * j + 128 * hl;         // this lane's place in a tile
             floatx16 n2[NB], y[NB];
             {   // layer 1; its normalised pre-activations are worked out again where the backward pass needs them
                 // (12 matrix instructions) instead of being carried through the whole tile in 64 registers
                 floatx16 n1[NB];
                 first_layer<NB>(lds + P::a_f1, lane, x0, x1, x2, n1);
                 normalise<NB>(n1);
-                affine_relu_store<NB>(n1, lds + P::a_g1, lds + P::a_e1, hl, y, io.y1e + (size_t)p * LD, valid);
+                affine_relu_store<NB>(n1, lds + P::a_g1, lds + P::a_e1, hl, y, io.y1e + tile_off);
             }
-            if (valid && hl == 0) *reinterpret_cast<float4*>(io.y1e + (size_t)p * LD + H) = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
             unit_vector<NB>(lds + P::a_b2, hl, n2);
             hidden_layer<NB, false>(lds + P::a_f2, lane, y, n2);
             const float rstd2 = normalise<NB>(n2);
-            affine_relu_store<NB>(n2, lds + P::a_g2, lds + P::a_e2, hl, y, io.y2e + (size_t)p * LD, valid);
-            if (valid && hl == 0) *reinterpret_cast<float4*>(io.y2e + (size_t)p * LD + H) = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+            affine_relu_store<NB>(n2, lds + P::a_g2, lds + P::a_e2, hl, y, io.y2e + tile_off);
             // heads
             floatx16 h0 = {0}, h1 = {0};
             {
@@ -332,10 +335,10 @@ __global__ __launch_bounds__(ROWS_THREADS<ACTOR>) void ppo_rows_kernel(MarlPpoIO
             dh[3] = in1 ? glp * (z1 * z1 - 1.0f) + gent : 0.0f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) dh[4 + q] = glp * ((q == band ? 1.0f : 0.0f) - pr[q]) - gent * pr[q] * (lpk[q] + hcat);
-            if (valid) {
+            {
                 float4* out = reinterpret_cast<float4*>(io.dh + (size_t)p * 8);
                 out[hl] = hl ? make_float4(dh[4], dh[5], dh[6], dh[7]) : make_float4(dh[0], dh[1], dh[2], dh[3]);
-                if (hl == 0) {
+                if (valid && hl == 0) {
                     s_loss -= fminf(s1, s2);
                     s_ent += ent;
                     s_clip += fabsf(ratio - 1.0f) > io.clip_eps ? 1.0f : 0.0f;
@@ -355,17 +358,17 @@ __global__ __launch_bounds__(ROWS_THREADS<ACTOR>) void ppo_rows_kernel(MarlPpoIO
                 d[b] = c;
             });
             layer_norm_backward<NB>(d, n2, rstd2, lds + P::a_g2, lds + P::a_e2, hl, j, acc_e2, acc_g2);
-            store_units<NB>(d, hl, io.dz2 + (size_t)p * H, valid);
+            store_units<NB>(d, io.dz2 + tile_off);
             // dL/dy1 = W2^T dz2
             static_for<0, NB>([&](auto bb) { y[decltype(bb)::value] = floatx16{0}; });
             hidden_layer<NB, false>(lds + P::a_f2T, lane, d, y);
             first_layer<NB>(lds + P::a_f1, lane, x0, x1, x2, n2);          // n2 is free again: layer 1's pre-activations
             const float rstd1 = normalise<NB>(n2);
             layer_norm_backward<NB>(y, n2, rstd1, lds + P::a_g1, lds + P::a_e1, hl, j, acc_e1, acc_g1);
-            store_units<NB>(y, hl, io.dz1 + (size_t)p * H, valid);
+            store_units<NB>(y, io.dz1 + tile_off);
         }
-        if ((j & 16) == 0) {                  // this wave's sums over its tiles: (bias 1, weight 1, bias 2, weight 2) x H
-            float* out = io.ln_sums + (size_t)(blockIdx.x * WAVES + wave) * 4 * H;
+        if ((j & 16) == 0) {                  // this wave's sums over its tiles, see MarlPpoIO.actor_sums
+            float* out = io.actor_sums + (size_t)(blockIdx.x * WAVES + wave) * 4 * H;
             static_for<0, NB>([&](auto bb) {
                 constexpr int b = decltype(bb)::value;
                 const int u = scattered_unit(b, j, hl);
@@ -408,14 +411,13 @@ __global__ __launch_bounds__(ROWS_THREADS<ACTOR>) void ppo_rows_kernel(MarlPpoIO
             first_layer<NB>(cf1, lane, x0, x1, x2, y1);
             static_for<0, NB>([&](auto bb) { static_for<0, 16>([&](auto vv) {
                 y1[decltype(bb)::value][decltype(vv)::value] = fmaxf(y1[decltype(bb)::value][decltype(vv)::value], 0.0f); }); });
-            store_units<NB>(y1, hl, io.cy1e + (size_t)p * LD, valid);
-            if (valid && hl == 0) *reinterpret_cast<float4*>(io.cy1e + (size_t)p * LD + H) = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+            const size_t tile_off = (size_t)tile * 32 * H + 4 * j + 128 * hl;
+            store_units<NB>(y1, io.cy1e + tile_off);
             unit_vector<NB>(cb2, hl, y2);
             hidden_layer<NB>(cf2, lane, y1, y2);
             static_for<0, NB>([&](auto bb) { static_for<0, 16>([&](auto vv) {
                 y2[decltype(bb)::value][decltype(vv)::value] = fmaxf(y2[decltype(bb)::value][decltype(vv)::value], 0.0f); }); });
-            store_units<NB>(y2, hl, io.cy2e + (size_t)p * LD, valid);
-            if (valid && hl == 0) *reinterpret_cast<float4*>(io.cy2e + (size_t)p * LD + H) = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+            store_units<NB>(y2, io.cy2e + tile_off);
             float v = 0.0f;
             const float* w3b = cw3 + opaque(4 * hl);
             static_for<0, NB>([&](auto bb) {
@@ -434,10 +436,9 @@ __global__ __launch_bounds__(ROWS_THREADS<ACTOR>) void ppo_rows_kernel(MarlPpoIO
             v += cb3;
             const float err = v - in.ret;
             const float dv = valid ? 2.0f * io.c1 * err * inv_b : 0.0f;                 // d(c1 mean (v - ret)^2)/dv
-            if (valid && hl == 0) {
-                io.dv[p] = dv;
-                s_vloss = fmaf(io.c1 * err, err, s_vloss);
-            }
+            if (hl == 0) io.dv[p] = dv;
+            if (valid && hl == 0) s_vloss = fmaf(io.c1 * err, err, s_vloss);
+
             // dz2 = w3 dv where y2 > 0; dy1 = W2^T dz2; dz1 = dy1 where y1 > 0
             static_for<0, NB>([&](auto bb) {
                 constexpr int b = decltype(bb)::value;
@@ -451,7 +452,8 @@ __global__ __launch_bounds__(ROWS_THREADS<ACTOR>) void ppo_rows_kernel(MarlPpoIO
                     LDS_FENCE();
                 });
             });
-            store_units<NB>(y2, hl, io.cdz2 + (size_t)p * H, valid);
+            store_units<NB>(y2, io.cdz2 + tile_off);
+
             floatx16 dy[NB];
             static_for<0, NB>([&](auto bb) { dy[decltype(bb)::value] = floatx16{0}; });
             hidden_layer<NB>(cf2T, lane, y2, dy);
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(ROWS_THREADS<ACTOR>) void ppo_rows_kernel(MarlPpoIO
             static_for<0, NB>([&](auto bb) { static_for<0, 16>([&](auto vv) {
                 constexpr int b = decltype(bb)::value, q = decltype(vv)::value;
                 dy[b][q] = y1[b][q] > 0.0f ? dy[b][q] : 0.0f; }); });
-            store_units<NB>(dy, hl, io.cdz1 + (size_t)p * H, valid);
+            store_units<NB>(dy, io.cdz1 + tile_off);
         }
         s_vloss = wave_total(s_vloss);
         if (lane == 0 && io.stats) atomicAdd(io.stats + 1, (double)s_vloss);
@@ -467,20 +469,27 @@ __global__ __launch_bounds__(ROWS_THREADS<ACTOR>) void ppo_rows_kernel(MarlPpoIO
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Sums over rows: the six products (row matrix)^T (row matrix) that turn what ppo_rows_kernel wrote into parameter
-// gradients, in ONE pass over the arrays.  The arrays are row-major [B][.], which is the operand layout a
-// contraction over rows wants: step s of a product takes rows 2 s and 2 s + 1, lane l the element of row
-// 2 s + l / 32 in column 32 block + l % 32 -- two full 128-byte lines per load.  A workgroup owns a run of rows;
-// waves 0..3 take the actor's products (wave w: row block w of dz2^T y1e and dz1^T xe, column block w of dh^T y2e),
-// waves 4..7 the critic's; each workgroup leaves its partial 32 x 32 blocks in `partial`, summed by the caller.
+// Sums over rows: the six products (row matrix)^T (row matrix) that turn what the row pass wrote into parameter
+// gradients, in ONE pass over the arrays.  A workgroup walks over tiles of 32 rows: all 512 threads bring a tile
+// of the eight big arrays in with 16-byte loads (the tile-major layout makes them contiguous), one tile ahead in
+// registers, and lay it down in LDS row by row; there the operand of a contraction over rows is a plain 4-byte
+// read: step s takes rows 2 s and 2 s + 1, lane l the element of row 2 s + l / 32 in column 32 block + l % 32.
+// Waves 0..3 take the actor's products (wave w: row block w of dz2^T y1 and of dz1^T xe, column block w of
+// dh^T y2), waves 4..7 the critic's; every workgroup leaves its partial 32 x 32 blocks in `partial`, summed by
+// the caller (fixed order: deterministic).
 template <int H>
 struct ProductLayout {
-    static constexpr int NBO = H / 32, NBJ = (H + 4 + 31) / 32, LDO = NBJ * 32;
-    static constexpr int g2 = 0;                          // [H][LDO]   dz2^T y1e
-    static constexpr int g1 = g2 + H * LDO;               // [H][32]    dz1^T xe
-    static constexpr int gh = g1 + H * 32;                // [32][LDO]  dh^T y2e (rows 0..7)
-    static constexpr int half = gh + 32 * LDO;            // the critic's three follow in the same order
+    static constexpr int NBO = H / 32;
+    static constexpr int g2 = 0;                          // [H][H]   dz2^T y1
+    static constexpr int g1 = g2 + H * H;                 // [H][32]  dz1^T xe (columns 0..4 the weights, 5 the bias)
+    static constexpr int gh = g1 + H * 32;                // [32][H]  dh^T y2 (rows 0..7; the critic's: row 0)
+    static constexpr int gb = gh + 32 * H;                // [H][32]  dz2^T xe: column 5 (xe's ones) = the bias of layer 2
+    static constexpr int ghb = gb + H * 32;               // [32][32] dh^T xe: column 5 = the head biases
+    static constexpr int half = ghb + 32 * 32;            // the critic's five follow in the same order
     static constexpr int total = 2 * half;
+    static constexpr int LD = H + 4;                      // LDS row pitch (floats)
+    static constexpr int ARR = 32 * LD;
+    static constexpr int lds_floats = 8 * ARR + 32 * 8 + 32 * 8 + 32;
 };
 
 __device__ __forceinline__ void store_block(const floatx16& c, float* __restrict__ out, int ldo, int lane) {
@@ -489,105 +498,126 @@ __device__ __forceinline__ void store_block(const floatx16& c, float* __restrict
     for (int v = 0; v < 16; ++v) out[(size_t)(8 * (v / 4) + 4 * hl + v % 4) * ldo + j] = c[v];
 }
 
-// One wave's share of the products, specialised on what the wave owns so that the loops carry no conditions:
-// ROWS = row block w of the two hidden-layer products, FIRST / SECOND = column blocks w and w + 4 of the head product.
-template <int H, bool ROWS, bool FIRST, bool SECOND>
-__device__ __forceinline__ void products_body(const MarlPpoIO& io, int B, float* __restrict__ out, int w, bool critic, int lane,
-                                              int s0, int s1) {
-    using L = ProductLayout<H>;
-    constexpr int NBJ = L::NBJ, LD = H + 4, U = 4;
-    const int i = lane & 31, kh = lane >> 5;
-    const float* dzb = critic ? io.cdz2 : io.dz2;          // [B][H]
-    const float* dza = critic ? io.cdz1 : io.dz1;          // [B][H]
-    const float* y1 = critic ? io.cy1e : io.y1e;           // [B][LD]
-    const float* y2 = critic ? io.cy2e : io.y2e;           // [B][LD]
-    const float* hd = critic ? io.dv : io.dh;              // critic: [B] (one head), actor: [B][8]
-    const int heads = critic ? 1 : 8, hstride = critic ? 1 : 8;
-    floatx16 acc2[NBJ], acc1 = {0}, acch0 = {0}, acch1 = {0};
-    static_for<0, NBJ>([&](auto cc) { acc2[decltype(cc)::value] = floatx16{0}; });
-    // Loads carry no branches: addresses are clamped into the arrays, and what lies beyond the minibatch or beyond a
-    // row's columns is zeroed through the A operand or the column masks.
-    const int hcol = i < heads ? i : 0, xcol = i < 8 ? i : 0;
-    const float hmask = i < heads ? 1.0f : 0.0f, xmask = i < 8 ? 1.0f : 0.0f;
-    int ycol[NBJ];
-    float ymask[NBJ];
-    static_for<0, NBJ>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        ycol[c] = 32 * c + i < LD ? 32 * c + i : LD - 1;
-        ymask[c] = 32 * c + i < LD ? 1.0f : 0.0f;
-    });
-    const int hc0 = 32 * w + i, hc1 = 32 * (w + 4) + i;      // this wave's columns of the head product
-    const int hcol0 = hc0 < LD ? hc0 : LD - 1, hcol1 = hc1 < LD ? hc1 : LD - 1;
-    const float hm0 = hc0 < LD ? 1.0f : 0.0f, hm1 = hc1 < LD ? 1.0f : 0.0f;
-    // Software pipeline: the loads of batch n + 1 (U steps) are in flight while the matrix instructions of batch n run
-    // (two batches ahead does not fit the registers: 73 spills, 1.2 ms instead of 0.45).
-    struct Batch { float ah[U], bh0[U], bh1[U], a2[U], a1[U], bx[U], by[U][NBJ]; };
-    auto load = [&](int sb, Batch& t) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int r = 2 * (sb + u) + kh;
-            const bool ok = sb + u < s1 && r < B;
-            const size_t rr = ok ? (size_t)r : (size_t)(B - 1);
-            const float live = ok ? 1.0f : 0.0f;
-            if constexpr (FIRST || SECOND) t.ah[u] = hd[rr * hstride + hcol] * (hmask * live);
-            if constexpr (FIRST) t.bh0[u] = y2[rr * LD + hcol0] * hm0;
-            if constexpr (SECOND) t.bh1[u] = y2[rr * LD + hcol1] * hm1;
-            if constexpr (ROWS) {
-                t.a2[u] = dzb[rr * H + 32 * w + i] * live;
-                t.a1[u] = dza[rr * H + 32 * w + i] * live;
-                t.bx[u] = io.xe[rr * 8 + xcol] * xmask;
-                static_for<0, NBJ>([&](auto cc) {
-                    constexpr int c = decltype(cc)::value;
-                    t.by[u][c] = y1[rr * LD + ycol[c]] * ymask[c];
-                });
-            }
-        }
-    };
-    Batch cur, nxt;
-    if (s0 < s1) load(s0, cur);
-    for (int sb = s0; sb < s1; sb += U) {
-        if (sb + U < s1) load(sb + U, nxt);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if constexpr (FIRST) acch0 = mfma(cur.ah[u], cur.bh0[u], acch0);
-            if constexpr (SECOND) acch1 = mfma(cur.ah[u], cur.bh1[u], acch1);
-            if constexpr (ROWS) {
-                acc1 = mfma(cur.a1[u], cur.bx[u], acc1);
-                static_for<0, NBJ>([&](auto cc) {
-                    constexpr int c = decltype(cc)::value;
-                    acc2[c] = mfma(cur.a2[u], cur.by[u][c], acc2[c]);
-                });
-            }
-        }
-        cur = nxt;
-    }
-    if constexpr (ROWS) {
-        static_for<0, NBJ>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            store_block(acc2[c], out + L::g2 + (size_t)32 * w * L::LDO + 32 * c, L::LDO, lane);
-        });
-        store_block(acc1, out + L::g1 + (size_t)32 * w * 32, 32, lane);
-    }
-    if constexpr (FIRST) store_block(acch0, out + L::gh + 32 * w, L::LDO, lane);
-    if constexpr (SECOND) store_block(acch1, out + L::gh + 32 * (w + 4), L::LDO, lane);
-}
-
 template <int H>
-__global__ __launch_bounds__(PPO_THREADS) void ppo_products_kernel(MarlPpoIO io, int B, float* __restrict__ partial) {
+__global__ __launch_bounds__(PPO_THREADS) void ppo_products_kernel(MarlPpoIO io, int tiles, float* __restrict__ partial) {
     using L = ProductLayout<H>;
-    constexpr int NBO = L::NBO, NBJ = L::NBJ;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: scalar branches
+    constexpr int NBO = L::NBO, LD = L::LD, ARR = L::ARR, PER = H / 64;      // 16-byte pieces of a tile per thread and array
+    extern __shared__ __align__(16) float lds[];
+    float* lx = lds + 8 * ARR;
+    float* ldh = lx + 32 * 8;
+    float* ldv = ldh + 32 * 8;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kh = lane >> 5;
     const bool critic = wave >= 4;
     const int w = wave & 3;
-    const int steps = (B + 1) / 2;
-    const int per = (steps + gridDim.x - 1) / gridDim.x;
-    const int s0 = blockIdx.x * per, s1 = min(steps, s0 + per);
+    const float* src[8] = {io.dz2, io.y1e, io.dz1, io.y2e, io.cdz2, io.cy1e, io.cdz1, io.cy2e};
+    typedef float floatx4 __attribute__((ext_vector_type(4)));      // (HIP's float4 is a union type: arrays of it stay in scratch)
+    floatx4 st[8][PER], sx = {0, 0, 0, 0};
+    float sdv = 0.0f;
+    // (every index of st is a constant when the loops are expanded by static_for; a run-time loop index, even of a
+    // fully unrollable loop, sends the array to scratch memory)
+    auto fetch = [&](int tile) {
+        static_for<0, 8>([&](auto aa) {
+            constexpr int a = decltype(aa)::value;
+            const floatx4* p = reinterpret_cast<const floatx4*>(src[a] + (size_t)tile * 32 * H);
+            static_for<0, PER>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                st[a][k] = p[tid + PPO_THREADS * k];
+            });
+        });
+        if (tid < 64) sx = reinterpret_cast<const floatx4*>(io.xe + (size_t)tile * 32 * 8)[tid];
+        else if (tid < 128) sx = reinterpret_cast<const floatx4*>(io.dh + (size_t)tile * 32 * 8)[tid - 64];
+        else if (tid < 160) sdv = io.dv[(size_t)tile * 32 + tid - 128];
+    };
+    auto lay_down = [&]() {
+        static_for<0, 8>([&](auto aa) {
+            constexpr int a = decltype(aa)::value;
+            static_for<0, PER>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                const int f = tid + PPO_THREADS * k;             // piece f of the tile = chunk f / 32 (units 4 c ..), row f % 32
+                *reinterpret_cast<floatx4*>(lds + a * ARR + (f & 31) * LD + 4 * (f >> 5)) = st[a][k];
+            });
+        });
+        if (tid < 64) reinterpret_cast<floatx4*>(lx)[tid] = sx;
+        else if (tid < 128) reinterpret_cast<floatx4*>(ldh)[tid - 64] = sx;
+        else if (tid < 160) ldv[tid - 128] = sdv;
+    };
+    // The big product runs on the matrix cores; the narrow ones (6 columns of xe, 8 heads, the bias sums) are a few
+    // multiply-adds per step on the vector pipe beside them: lane (unit i of block w, row parity) keeps its own
+    // sums over the rows of its parity, the two parities meet at the end.
+    floatx16 acc2[NBO];
+    float s1[6] = {}, sh[8] = {}, sb = 0.0f, shb = 0.0f;
+    static_for<0, NBO>([&](auto cc) { acc2[decltype(cc)::value] = floatx16{0}; });
+    const float* A2 = lds + (critic ? 4 : 0) * ARR;
+    const float* Y1 = A2 + ARR;
+    const float* A1 = A2 + 2 * ARR;
+    const float* Y2 = A2 + 3 * ARR;
+    const int col = 32 * w + i;
+    const int i8 = i & 7;
+    int tile = blockIdx.x;
+    if (tile < tiles) fetch(tile);
+    for (; tile < tiles; tile += gridDim.x) {
+        __syncthreads();                                   // the tile before has been consumed
+        lay_down();
+        __syncthreads();
+        if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
+        if (w < NBO) {
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) {
+                const int row = 2 * s + kh;
+                const float a2 = A2[row * LD + col], a1 = A1[row * LD + col], bh = Y2[row * LD + col];
+                const float4 xa = *reinterpret_cast<const float4*>(lx + row * 8), xb = *reinterpret_cast<const float4*>(lx + row * 8 + 4);
+                s1[0] = fmaf(a1, xa.x, s1[0]); s1[1] = fmaf(a1, xa.y, s1[1]); s1[2] = fmaf(a1, xa.z, s1[2]);
+                s1[3] = fmaf(a1, xa.w, s1[3]); s1[4] = fmaf(a1, xb.x, s1[4]); s1[5] = fmaf(a1, xb.y, s1[5]);
+                sb += a2;
+                if (critic) {
+                    const float dv = ldv[row];
+                    sh[0] = fmaf(dv, bh, sh[0]);
+                    shb += dv;
+                } else {
+                    const float4 ha = *reinterpret_cast<const float4*>(ldh + row * 8), hb = *reinterpret_cast<const float4*>(ldh + row * 8 + 4);
+                    sh[0] = fmaf(ha.x, bh, sh[0]); sh[1] = fmaf(ha.y, bh, sh[1]); sh[2] = fmaf(ha.z, bh, sh[2]); sh[3] = fmaf(ha.w, bh, sh[3]);
+                    sh[4] = fmaf(hb.x, bh, sh[4]); sh[5] = fmaf(hb.y, bh, sh[5]); sh[6] = fmaf(hb.z, bh, sh[6]); sh[7] = fmaf(hb.w, bh, sh[7]);
+                    shb += ldh[row * 8 + i8];                    // lane i < 8: the sum of head i's gradients
+                }
+                static_for<0, NBO>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    acc2[c] = mfma(a2, Y1[row * LD + 32 * c + i], acc2[c]);
+                });
+            }
+        }
+    }
     float* out = partial + (size_t)blockIdx.x * L::total + (critic ? L::half : 0);
-    const bool rows = w < NBO, first = w < NBJ, second = w + 4 < NBJ;
-    if (rows && second) products_body<H, true, true, true>(io, B, out, w, critic, lane, s0, s1);
-    else if (rows) products_body<H, true, true, false>(io, B, out, w, critic, lane, s0, s1);      // NBO <= NBJ: rows imply first
-    else if (first) products_body<H, false, true, false>(io, B, out, w, critic, lane, s0, s1);
+    if (w < NBO) {
+        static_for<0, NBO>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            store_block(acc2[c], out + L::g2 + (size_t)32 * w * H + 32 * c, H, lane);
+        });
+        // the narrow products: both row parities together, then lane i (of the lower half) writes unit 32 w + i
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s1[k] += __shfl_xor(s1[k], 32);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sh[k] += __shfl_xor(sh[k], 32);
+        sb += __shfl_xor(sb, 32);
+        shb += __shfl_xor(shb, 32);
+        if (kh == 0) {
+            float* g1 = out + L::g1 + (size_t)col * 32;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) g1[k] = s1[k];
+#pragma unroll
+            for (int k = 6; k < 32; ++k) g1[k] = 0.0f;
+            float* gb = out + L::gb + (size_t)col * 32;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) gb[k] = k == 5 ? sb : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) out[L::gh + (size_t)k * H + col] = sh[k];
+            for (int k = 8; k < 32; ++k) out[L::gh + (size_t)k * H + col] = 0.0f;
+            if (w == 0) {
+                for (int k = 0; k < 32; ++k) out[L::ghb + i * 32 + k] = (k == 5 && i < (critic ? 1 : 8)) ? shb : 0.0f;
+            }
+        }
+    }
 }
 
 int g_ppo_cus = 0;
@@ -616,7 +646,7 @@ static int ppo_cus() {
     return g_ppo_cus;
 }
 
-int32_t marl_ppo_ln_rows(void) { return ppo_cus() * PPO_WAVES; }
+int32_t marl_ppo_sum_rows(void) { return ppo_cus() * (ROWS_THREADS<false> / WAVE); }
 
 int32_t marl_ppo_partial_rows(void) { return ppo_cus(); }
 
@@ -635,12 +665,25 @@ int marl_ppo_products(int32_t B, int32_t hidden, const MarlPpoIO* io, float* par
         io->dh == nullptr || io->cy1e == nullptr || io->cy2e == nullptr || io->cdz1 == nullptr || io->cdz2 == nullptr ||
         io->dv == nullptr)
         return MARL_EINVAL;
-    const int grid = ppo_cus();                 // every workgroup writes its partial blocks (zeros if it has no rows)
-    if (hidden == 64)
-        hipLaunchKernelGGL(ppo_products_kernel<64>, dim3(grid), dim3(PPO_THREADS), 0, (hipStream_t)stream, *io, (int)B, partial);
-    else
-        hipLaunchKernelGGL(ppo_products_kernel<128>, dim3(grid), dim3(PPO_THREADS), 0, (hipStream_t)stream, *io, (int)B, partial);
-    const hipError_t err = hipGetLastError();
+    const int grid = ppo_cus();                 // every workgroup writes its partial blocks (zeros if it has no tile)
+    const int tiles = (B + 31) / 32;
+    hipError_t err = hipSuccess;
+#define MARL_LAUNCH_PRODUCTS(HH)                                                                                     \
+    do {                                                                                                              \
+        static bool attr_set = false;                                                                                 \
+        const size_t lds_bytes = (size_t)ProductLayout<HH>::lds_floats * sizeof(float);                               \
+        if (!attr_set) {                                                                                              \
+            err = hipFuncSetAttribute((const void*)ppo_products_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)lds_bytes);                                                                \
+            attr_set = err == hipSuccess;                                                                             \
+        }                                                                                                             \
+        if (err == hipSuccess)                                                                                        \
+            hipLaunchKernelGGL(ppo_products_kernel<HH>, dim3(grid), dim3(PPO_THREADS), lds_bytes, (hipStream_t)stream, \
+                               *io, tiles, partial);                                                                  \
+    } while (0)
+    if (hidden == 64) MARL_LAUNCH_PRODUCTS(64); else MARL_LAUNCH_PRODUCTS(128);
+#undef MARL_LAUNCH_PRODUCTS
+    if (err == hipSuccess) err = hipGetLastError();
     if (err == hipSuccess) return MARL_OK;
     marl_note_hip_error((int)err);
     return MARL_EHIP;
@@ -651,14 +694,14 @@ int marl_ppo_rows(int32_t B, int32_t hidden, const MarlPpoIO* io, void* stream) 
     if (hidden != 64 && hidden != 128) return MARL_EUNSUPPORTED;
     if (io->weights == nullptr || io->obs == nullptr || io->actions == nullptr || io->old_log_probs == nullptr ||
         io->advantages == nullptr || io->returns == nullptr || io->xe == nullptr || io->y1e == nullptr ||
-        io->y2e == nullptr || io->dz1 == nullptr || io->dz2 == nullptr || io->ln_sums == nullptr ||
+        io->y2e == nullptr || io->dz1 == nullptr || io->dz2 == nullptr || io->actor_sums == nullptr ||
         io->dh == nullptr || io->cy1e == nullptr ||
         io->cy2e == nullptr || io->cdz1 == nullptr || io->cdz2 == nullptr || io->dv == nullptr)
         return MARL_EINVAL;
     const int tiles = (B + 31) / 32;
     const int cus = ppo_cus();                             // one workgroup per CU; fewer for a small minibatch
     // waves that do not run leave their rows of the partial sums at zero
-    hipError_t err = hipMemsetAsync(io->ln_sums, 0, (size_t)marl_ppo_ln_rows() * 4 * hidden * sizeof(float), (hipStream_t)stream);
+    hipError_t err = hipMemsetAsync(io->actor_sums, 0, (size_t)marl_ppo_sum_rows() * 4 * hidden * sizeof(float), (hipStream_t)stream);
 #define MARL_LAUNCH_PPO(HH, ACTOR, FLOATS)                                                                           \
     do {                                                                                                              \
         static bool attr_set = false;                                                                                 \

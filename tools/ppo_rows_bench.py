@@ -38,7 +38,7 @@ w = z["packer"].pack()
 io = _lib.MarlPpoIO()
 io.weights = w.data_ptr(); io.obs, io.actions, io.old_log_probs = obs.data_ptr(), act.data_ptr(), old.data_ptr()
 io.advantages, io.returns, io.index = adv.data_ptr(), ret.data_ptr(), idx.data_ptr()
-for k in ("xe", "y1e", "y2e", "dz1", "dz2", "ln_sums", "dh", "cy1e", "cy2e", "cdz1", "cdz2", "dv"):
+for k in ("xe", "y1e", "y2e", "dz1", "dz2", "actor_sums", "dh", "cy1e", "cy2e", "cdz1", "cdz2", "dv"):
     setattr(io, k, z[k].data_ptr())
 io.stats = z["stats"].data_ptr()
 io.clip_eps, io.c1, io.c2, io.v_max, io.log_std_min, io.log_std_max = 0.2, 0.5, 0.01, 5.0, -1.0, 0.5
