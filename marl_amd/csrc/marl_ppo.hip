@@ -210,12 +210,14 @@ __device__ __forceinline__ float wave_total(float v) {
 
 // ACTOR selects the network: one launch each (two bodies in one kernel are more code than the instruction cache
 // of a CU pair holds, and the workgroups of the lighter network would idle at the end).
-// (Three waves per SIMD for the critic's pass, which would fit its registers, gain nothing: the pass is bound by
-// what a CU shares -- the matrix pipes and the store path -- not by latency.)
-template <bool ACTOR> constexpr int ROWS_THREADS = PPO_THREADS;
+// Threads per workgroup.  The actor's tile at H = 128 wants more than the 256 registers a wave gets at two waves per
+// SIMD (131 spilled; every reload then waits for the tile's stores, loads and stores sharing one in-order
+// counter): with ONE wave per SIMD and 386 registers it is faster (0.31 against 0.35 ms), the second wave's overlap
+// notwithstanding.  (Three waves per SIMD for the critic's pass, which would fit its registers, gain nothing.)
+template <int H, bool ACTOR> constexpr int ROWS_THREADS = (ACTOR && H > 64) ? 256 : PPO_THREADS;
 template <int H, bool ACTOR>
-__global__ __launch_bounds__(ROWS_THREADS<ACTOR>) void ppo_rows_kernel(MarlPpoIO io, int B) {
-    constexpr int THREADS = ROWS_THREADS<ACTOR>, WAVES = THREADS / WAVE;
+__global__ __launch_bounds__((ROWS_THREADS<H, ACTOR>)) void ppo_rows_kernel(MarlPpoIO io, int B) {
+    constexpr int THREADS = ROWS_THREADS<H, ACTOR>, WAVES = THREADS / WAVE;
     using P = TrainPack<H>;
     constexpr int NB = P::NB, NS = P::NS;
     extern __shared__ __align__(16) float lds[];
@@ -646,7 +648,7 @@ static int ppo_cus() {
     return g_ppo_cus;
 }
 
-int32_t marl_ppo_sum_rows(void) { return ppo_cus() * (ROWS_THREADS<false> / WAVE); }
+int32_t marl_ppo_sum_rows(void) { return ppo_cus() * (PPO_THREADS / WAVE); }
 
 int32_t marl_ppo_partial_rows(void) { return ppo_cus(); }
 
@@ -711,10 +713,10 @@ int marl_ppo_rows(int32_t B, int32_t hidden, const MarlPpoIO* io, void* stream) 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                    \
             attr_set = err == hipSuccess;                                                                             \
         }                                                                                                             \
-        const int waves = ROWS_THREADS<ACTOR> / WAVE;                                                                 \
+        const int waves = ROWS_THREADS<HH, ACTOR> / WAVE;                                                             \
         const int grid = tiles < cus * waves ? (tiles + waves - 1) / waves : cus;                                     \
         if (err == hipSuccess)                                                                                        \
-            hipLaunchKernelGGL((ppo_rows_kernel<HH, ACTOR>), dim3(grid), dim3(ROWS_THREADS<ACTOR>), lds_bytes,       \
+            hipLaunchKernelGGL((ppo_rows_kernel<HH, ACTOR>), dim3(grid), dim3(ROWS_THREADS<HH, ACTOR>), lds_bytes,   \
                                (hipStream_t)stream, *io, (int)B);                                                     \
     } while (0)
     if (hidden == 64) {
