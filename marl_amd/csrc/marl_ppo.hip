@@ -272,7 +272,7 @@ __global__ __launch_bounds__((ROWS_THREADS<H, ACTOR>)) void ppo_rows_kernel(Marl
                 affine_relu_store<NB>(n1, lds + P::a_g1, lds + P::a_e1, hl, y, io.y1e + tile_off);
             }
             unit_vector<NB>(lds + P::a_b2, hl, n2);
-            hidden_layer<NB, false>(lds + P::a_f2, lane, y, n2);
+            hidden_layer<NB>(lds + P::a_f2, lane, y, n2);
             const float rstd2 = normalise<NB>(n2);
             affine_relu_store<NB>(n2, lds + P::a_g2, lds + P::a_e2, hl, y, io.y2e + tile_off);
             // heads
@@ -363,7 +363,7 @@ __global__ __launch_bounds__((ROWS_THREADS<H, ACTOR>)) void ppo_rows_kernel(Marl
             store_units<NB>(d, io.dz2 + tile_off);
             // dL/dy1 = W2^T dz2
             static_for<0, NB>([&](auto bb) { y[decltype(bb)::value] = floatx16{0}; });
-            hidden_layer<NB, false>(lds + P::a_f2T, lane, d, y);
+            hidden_layer<NB>(lds + P::a_f2T, lane, d, y);
             first_layer<NB>(lds + P::a_f1, lane, x0, x1, x2, n2);          // n2 is free again: layer 1's pre-activations
             const float rstd1 = normalise<NB>(n2);
             layer_norm_backward<NB>(y, n2, rstd1, lds + P::a_g1, lds + P::a_e1, hl, j, acc_e1, acc_g1);
