@@ -652,10 +652,10 @@ class PPOAgent:
                  (self.actor.band_head.weight, gh[4:8]), (self.actor.band_head.bias, ghb[4:8, 5]),
                  (n[0].weight, c1[:, :5]), (n[0].bias, c1[:, 5]), (n[2].weight, c2), (n[2].bias, cb[:, 5]),
                  (n[4].weight, c3[0:1]), (n[4].bias, chb[0:1, 5])]
-        for p, g in grads:
+        for p, _ in grads:
             if p.grad is None:
                 p.grad = torch.empty_like(p)
-            p.grad.copy_(g.reshape(p.shape))
+        torch._foreach_copy_([p.grad for p, _ in grads], [g.reshape(p.shape) for p, g in grads])     # one launch
         self._keep = (weights, idx)                       # the launch reads them after this call returns
         return z["stats"] / B
 
