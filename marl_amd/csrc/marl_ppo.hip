@@ -105,8 +105,8 @@ __device__ __forceinline__ void affine_relu_store(const floatx16 (&n)[NB], const
             r.w = fmaxf(fmaf(n[b][4 * q + 3], gq.w, eq.w), 0.0f);
             y[b][4 * q] = r.x; y[b][4 * q + 1] = r.y; y[b][4 * q + 2] = r.z; y[b][4 * q + 3] = r.w;
             *reinterpret_cast<float4*>(ob + (8 * b + 2 * q) * 128) = r;
-            LDS_FENCE();
         });
+        LDS_FENCE();                  // per block: eight reads in flight together (the pass has registers to spare)
     });
 }
 
@@ -188,8 +188,7 @@ __device__ __forceinline__ void layer_norm_backward(floatx16 (&d)[NB], const flo
         });
         accE[b] += reduce_scatter16(E, j);
         accG[b] += reduce_scatter16(G, j);
-        LDS_FENCE();
-    });
+    });                               // (no fence between the blocks: their exchange chains interleave)
     m1 += __shfl_xor(m1, 32);
     m2 += __shfl_xor(m2, 32);
     m1 *= 1.0f / H;

@@ -47,12 +47,13 @@ print("marl_ppo_rows alone     %.3f ms" % timed(lambda: _lib.check(_lib.load().m
 io.index = None
 print("  rows in order         %.3f ms" % timed(lambda: _lib.check(_lib.load().marl_ppo_rows(B, 128, C.byref(io), st))))
 print("pack                    %.3f ms" % timed(lambda: z["packer"].pack()))
-if os.environ.get("PPO_PHASES"):
+if os.environ.get("PPO_PHASES"):          # library built with the cycle stamps of the phase experiment
     io.index = idx.data_ptr()
     _lib.check(_lib.load().marl_ppo_rows(B, 128, C.byref(io), st)); torch.cuda.synchronize()
-    names = ["inputs", "layer 1 + LN + store", "layer 2", "LN 2 + store", "heads + losses", "heads^T + LN 2 backward", "W2^T product + store dz2", "layer 1 again + LN 1 backward + store"]
-    v = z["dh"].view(-1)[:9].cpu().tolist()
-    print("actor tile phases (cycles, one wave; %d tiles):" % int(v[8]))
+    names = ["inputs", "layer 1", "normalise 1", "affine + relu + store y1", "layer 2", "LN 2 + store y2", "heads", "losses",
+             "heads^T + LN 2 backward", "store dz2 + W2^T product", "layer 1 again + normalise", "LN 1 backward + store dz1"]
+    v = z["dh"].view(-1)[:13].cpu().tolist()
+    print("actor tile phases (cycles, one wave; %d tiles):" % int(v[12]))
     for n_, c in zip(names, v):
         print("   %-40s %9.0f" % (n_, c))
-    print("   %-40s %9.0f" % ("sum", sum(v[:8])))
+    print("   %-40s %9.0f" % ("sum", sum(v[:12])))
