@@ -375,6 +375,13 @@ int32_t marl_ppo_partial_rows(void);
 size_t marl_ppo_partial_floats(int32_t hidden);
 int marl_ppo_products(int32_t B, int32_t hidden, const MarlPpoIO *io, float *partial, void *stream);
 
+/* The gradients in the caller's parameter order: out[t] = the sum over the slabs of partial[.][index[t]] when index[t] >= 0,
+ * over the rows of actor_sums[.][-index[t] - 1] otherwise (index: device memory, built once from the slab layout above;
+ * marl_amd.agents.PPOAgent points every parameter's .grad into `out`, so that the all-reduce, the clipping and Adam of
+ * ppo_agent.py:324-331 follow without a copy).  Fixed order of addition: the same input gives the same bits. */
+int marl_ppo_reduce(int32_t n_out, const int32_t *index, int32_t hidden, const float *partial, const float *actor_sums,
+                    float *out, void *stream);
+
 /* The enemy-noise draw the step kernel uses when MarlStepIO.noise is NULL,
  * written out as [E][N][2] for step numbers step_count[e] + 1. */
 int marl_fill_noise(const MarlEnvParams *p, const MarlEnvState *s, uint64_t seed,

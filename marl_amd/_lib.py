@@ -128,6 +128,7 @@ SYMBOLS = {
     "marl_ppo_partial_rows": (C.c_int32, []),
     "marl_ppo_partial_floats": (C.c_size_t, [C.c_int32]),
     "marl_ppo_products": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(MarlPpoIO), _pf, C.c_void_p]),
+    "marl_ppo_reduce": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, _pf, _pf, _pf, C.c_void_p]),
     "marl_ppo_rows": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(MarlPpoIO), C.c_void_p]),
     "marl_fill_noise": (C.c_int, [C.POINTER(MarlEnvParams), C.POINTER(MarlEnvState), C.c_uint64, C.c_uint64,
                                   _pd, C.c_void_p]),

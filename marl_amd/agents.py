@@ -593,6 +593,7 @@ class PPOAgent:
             if n != packer.gather.numel():
                 raise _lib.MarlError(f"packed training weights: {packer.gather.numel()} floats, the library expects {n}")
             self._fz = {"B": 0, "packer": packer, "stats": torch.zeros(5, dtype=torch.float64, device=self.device)}
+            self._fz["gindex"], self._fz["gflat"] = self._gradient_layout()
         z = self._fz
         if z["B"] < B:
             f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=self.device)
@@ -604,6 +605,41 @@ class PPOAgent:
             if "partial" not in z:
                 z["partial"] = f(lib.marl_ppo_partial_rows(), lib.marl_ppo_partial_floats(H))
         return z
+
+    def _gradient_layout(self):
+        """Where every parameter gradient sits in what marl_ppo_products / marl_ppo_rows leave behind (include/marl_env.h):
+        an int32 index per element of the flat gradient vector -- >= 0: offset in a workgroup slab, < 0: -(offset in a
+        wave's actor_sums row) - 1 -- and that vector, with every .grad pointed into it."""
+        H = self.hidden_dim
+        sizes = (H * H, H * 32, 32 * H, H * 32, 32 * 32)      # dz2^T y1, dz1^T xe, dh^T y2, dz2^T xe, dh^T xe
+        half = sum(sizes)
+
+        def cut(base):
+            out, o = [], base
+            for n_, shape in zip(sizes, ((H, H), (H, 32), (32, H), (H, 32), (32, 32))):
+                out.append(torch.arange(o, o + n_, dtype=torch.int64).view(shape))
+                o += n_
+            return out
+
+        g2, g1, gh, gb, ghb = cut(0)
+        c2, c1, c3, cb, chb = cut(half)
+        ln = -(torch.arange(4 * H, dtype=torch.int64) + 1)   # LayerNorm 1 bias, weight, LayerNorm 2 bias, weight (H each)
+        t, n = self.actor.trunk, self.critic.network
+        where = {t[0].weight: g1[:, :5], t[0].bias: g1[:, 5], t[1].weight: ln[H:2 * H], t[1].bias: ln[:H],
+                 t[3].weight: g2, t[3].bias: gb[:, 5], t[4].weight: ln[3 * H:4 * H], t[4].bias: ln[2 * H:3 * H],
+                 self.actor.mu_head.weight: gh[0:2], self.actor.mu_head.bias: ghb[0:2, 5],
+                 self.actor.log_std_head.weight: gh[2:4], self.actor.log_std_head.bias: ghb[2:4, 5],
+                 self.actor.band_head.weight: gh[4:8], self.actor.band_head.bias: ghb[4:8, 5],
+                 n[0].weight: c1[:, :5], n[0].bias: c1[:, 5], n[2].weight: c2, n[2].bias: cb[:, 5],
+                 n[4].weight: c3[0:1], n[4].bias: chb[0:1, 5]}
+        params = list(self.actor.parameters()) + list(self.critic.parameters())
+        index = torch.cat([where[p].reshape(-1) for p in params]).to(torch.int32).to(self.device)
+        flat = torch.zeros(index.numel(), dtype=torch.float32, device=self.device)
+        o = 0
+        for p in params:
+            p.grad = flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+        return index, flat
 
     def _fused_forward_backward(self, obs, actions, old_log_probs, advantages, returns, idx) -> torch.Tensor:
         """_forward_backward for the rows `idx` of the flat rollout tensors, without gathering them: one marl_ppo_rows
@@ -626,36 +662,12 @@ class PPOAgent:
             _lib.check(_lib.load().marl_ppo_rows(B, H, C.byref(io), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                        "marl_ppo_rows")
         lib = _lib.load()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         with torch.cuda.device(self.device):
-            _lib.check(lib.marl_ppo_products(B, H, C.byref(io), z["partial"].data_ptr(),
-                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "marl_ppo_products")
-        # one slab per workgroup -> their sum; then cut into the six products (include/marl_env.h)
-        tot = z["partial"].sum(0)
-        sizes = (H * H, H * 32, 32 * H, H * 32, 32 * 32)      # dz2^T y1, dz1^T xe, dh^T y2, dz2^T xe, dh^T xe
-        half = sum(sizes)
-
-        def cut(base):
-            out, o = [], base
-            for n_, shape in zip(sizes, ((H, H), (H, 32), (32, H), (H, 32), (32, 32))):
-                out.append(tot[o:o + n_].view(shape))
-                o += n_
-            return out
-
-        g2, g1, gh, gb, ghb = cut(0)
-        c2, c1, c3, cb, chb = cut(half)
-        t, n = self.actor.trunk, self.critic.network
-        ln = z["actor_sums"].sum(0)              # LayerNorm 1 bias, weight, LayerNorm 2 bias, weight (H each)
-        grads = [(t[0].weight, g1[:, :5]), (t[0].bias, g1[:, 5]), (t[1].weight, ln[H:2 * H]), (t[1].bias, ln[:H]),
-                 (t[3].weight, g2), (t[3].bias, gb[:, 5]), (t[4].weight, ln[3 * H:4 * H]), (t[4].bias, ln[2 * H:3 * H]),
-                 (self.actor.mu_head.weight, gh[0:2]), (self.actor.mu_head.bias, ghb[0:2, 5]),
-                 (self.actor.log_std_head.weight, gh[2:4]), (self.actor.log_std_head.bias, ghb[2:4, 5]),
-                 (self.actor.band_head.weight, gh[4:8]), (self.actor.band_head.bias, ghb[4:8, 5]),
-                 (n[0].weight, c1[:, :5]), (n[0].bias, c1[:, 5]), (n[2].weight, c2), (n[2].bias, cb[:, 5]),
-                 (n[4].weight, c3[0:1]), (n[4].bias, chb[0:1, 5])]
-        for p, _ in grads:
-            if p.grad is None:
-                p.grad = torch.empty_like(p)
-        torch._foreach_copy_([p.grad for p, _ in grads], [g.reshape(p.shape) for p, g in grads])     # one launch
+            _lib.check(lib.marl_ppo_products(B, H, C.byref(io), z["partial"].data_ptr(), st), "marl_ppo_products")
+            # per-workgroup slabs and per-wave rows -> the flat gradient vector every .grad is a view of
+            _lib.check(lib.marl_ppo_reduce(z["gindex"].numel(), z["gindex"].data_ptr(), H, z["partial"].data_ptr(),
+                                           z["actor_sums"].data_ptr(), z["gflat"].data_ptr(), st), "marl_ppo_reduce")
         self._keep = (weights, idx)                       # the launch reads them after this call returns
         return z["stats"] / B
 

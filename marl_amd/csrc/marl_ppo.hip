@@ -621,6 +621,37 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_products_kernel(MarlPpoIO io,
     }
 }
 
+// out[t] = the sum over the workgroup slabs of partial[.][index[t]] (index[t] >= 0) or over the wave rows of
+// sums[.][-index[t] - 1]: the parameter gradients in the caller's order, in one launch and a fixed order of addition.
+__global__ __launch_bounds__(1024) void ppo_reduce_kernel(int n_out, const int32_t* __restrict__ index,
+                                                          const float* __restrict__ partial, int n_slabs, size_t slab_floats,
+                                                          const float* __restrict__ sums, int n_rows, int row_floats,
+                                                          float* __restrict__ out) {
+    // 32 outputs per workgroup (neighbouring threads: neighbouring addresses), each summed by 32 threads that take
+    // every 32nd slab / row, then one pass through LDS
+    __shared__ float red[32][33];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int t = blockIdx.x * 32 + tx;
+    float a0 = 0.0f, a1 = 0.0f;
+    if (t < n_out) {
+        const int k = index[t];
+        const float* p = k >= 0 ? partial + k : sums + (-k - 1);
+        const size_t stride = k >= 0 ? slab_floats : (size_t)row_floats;
+        const int n = k >= 0 ? n_slabs : n_rows;
+        int s = ty;
+        for (; s + 32 < n; s += 64) { a0 += p[(size_t)s * stride]; a1 += p[(size_t)(s + 32) * stride]; }
+        if (s < n) a0 += p[(size_t)s * stride];
+    }
+    red[ty][tx] = a0 + a1;
+    __syncthreads();
+    if (ty == 0 && t < n_out) {
+        float v = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) v += red[r][tx];
+        out[t] = v;
+    }
+}
+
 int g_ppo_cus = 0;
 
 }  // namespace
@@ -685,6 +716,19 @@ int marl_ppo_products(int32_t B, int32_t hidden, const MarlPpoIO* io, float* par
     if (hidden == 64) MARL_LAUNCH_PRODUCTS(64); else MARL_LAUNCH_PRODUCTS(128);
 #undef MARL_LAUNCH_PRODUCTS
     if (err == hipSuccess) err = hipGetLastError();
+    if (err == hipSuccess) return MARL_OK;
+    marl_note_hip_error((int)err);
+    return MARL_EHIP;
+}
+
+int marl_ppo_reduce(int32_t n_out, const int32_t* index, int32_t hidden, const float* partial, const float* actor_sums,
+                    float* out, void* stream) {
+    if (n_out < 1 || index == nullptr || partial == nullptr || actor_sums == nullptr || out == nullptr) return MARL_EINVAL;
+    const size_t slab = marl_ppo_partial_floats(hidden);
+    if (slab == 0) return MARL_EUNSUPPORTED;
+    hipLaunchKernelGGL(ppo_reduce_kernel, dim3((n_out + 31) / 32), dim3(32, 32), 0, (hipStream_t)stream, (int)n_out, index, partial,
+                       (int)marl_ppo_partial_rows(), slab, actor_sums, (int)marl_ppo_sum_rows(), 4 * (int)hidden, out);
+    const hipError_t err = hipGetLastError();
     if (err == hipSuccess) return MARL_OK;
     marl_note_hip_error((int)err);
     return MARL_EHIP;
