@@ -735,7 +735,9 @@ class PPOAgent:
                 idx = perm[s:s + self.batch_size]
                 if self.fused_update:
                     out = self._fused_forward_backward(obs, actions, old_log_probs, advantages, returns, idx)
-                    self._sync.sync()
+                    if _dist_on() and torch.distributed.get_world_size() > 1:      # the gradients already are one flat vector
+                        torch.distributed.all_reduce(self._fz["gflat"])
+                        self._fz["gflat"].div_(torch.distributed.get_world_size())
                     self._apply_gradients()
                     acc += out
                     epoch_kl += out[4]
