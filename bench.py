@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="testing only: initialise torch.distributed (and so RCCL's streams) even with one rank")
     ap.add_argument("--share-device", action="store_true",
                     help="testing only: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
@@ -190,8 +192,12 @@ def main():
     dist = None
     if args.share_device:
         local_rank = 0
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
