@@ -382,6 +382,27 @@ int marl_ppo_products(int32_t B, int32_t hidden, const MarlPpoIO *io, float *par
 int marl_ppo_reduce(int32_t n_out, const int32_t *index, int32_t hidden, const float *partial, const float *actor_sums,
                     float *out, void *stream);
 
+/* Gradient-norm clip and Adam step of both networks (ppo_agent.py:324-325, 330-331: clip_grad_norm_(max_grad_norm) per
+ * network, then torch.optim.Adam with its default settings, betas / eps passed in) on flat float32 vectors of
+ * n = n_actor + n_critic elements, the actor's first: the gradients (read only: multiplied by grad_scale -- 1 / world
+ * size after a summing all-reduce -- and by the clip factor on the way in, not written back), the moments and the
+ * parameters (updated in place).  The four vectors are 16-byte aligned and hold ceil(n / 4) 4 floats, the padding zero.
+ * steps: one float32 counter per parameter tensor as torch.optim keeps them, tensors_actor then tensors_critic of
+ * them, each incremented; steps[0] and steps[tensors_actor] give the two bias corrections.  lr_actor, lr_critic:
+ * device scalars.  With n_packed > 0 the updated parameters are then laid out for the next marl_ppo_rows call:
+ * packed[j] = 0 where gather[j] == 0, else params[gather[j] - 1].  n <= 65 536 (these networks: 36 233). */
+typedef struct MarlPpoApply {
+    float *params, *exp_avg, *exp_avg_sq, *steps;
+    const float *grads;
+    const float *lr_actor, *lr_critic;
+    const int32_t *gather;       /* [n_packed] or NULL */
+    float *packed;               /* [n_packed] or NULL */
+    double beta1, beta2, eps;    /* as torch.optim.Adam holds them */
+    int32_t n_actor, n_critic, tensors_actor, tensors_critic, n_packed;
+    float max_norm, grad_scale;
+} MarlPpoApply;
+int marl_ppo_apply(const MarlPpoApply *a, void *stream);
+
 /* The enemy-noise draw the step kernel uses when MarlStepIO.noise is NULL,
  * written out as [E][N][2] for step numbers step_count[e] + 1. */
 int marl_fill_noise(const MarlEnvParams *p, const MarlEnvState *s, uint64_t seed,

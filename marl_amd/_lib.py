@@ -82,6 +82,16 @@ class MarlPpoIO(C.Structure):
     ]
 
 
+class MarlPpoApply(C.Structure):
+    _fields_ = [
+        ("params", _pf), ("exp_avg", _pf), ("exp_avg_sq", _pf), ("steps", _pf), ("grads", _pf),
+        ("lr_actor", _pf), ("lr_critic", _pf), ("gather", C.c_void_p), ("packed", _pf),
+        ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+        ("n_actor", C.c_int32), ("n_critic", C.c_int32), ("tensors_actor", C.c_int32), ("tensors_critic", C.c_int32),
+        ("n_packed", C.c_int32), ("max_norm", C.c_float), ("grad_scale", C.c_float),
+    ]
+
+
 class MarlResetIO(C.Structure):
     _fields_ = [
         ("mask", _pu8), ("enemy_pos", _pd), ("enemy_vel", _pd), ("enemy_omega", _pd), ("enemy_band", _pi), ("jam_init", _pd),
@@ -130,6 +140,7 @@ SYMBOLS = {
     "marl_ppo_products": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(MarlPpoIO), _pf, C.c_void_p]),
     "marl_ppo_reduce": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, _pf, _pf, _pf, C.c_void_p]),
     "marl_ppo_rows": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(MarlPpoIO), C.c_void_p]),
+    "marl_ppo_apply": (C.c_int, [C.POINTER(MarlPpoApply), C.c_void_p]),
     "marl_fill_noise": (C.c_int, [C.POINTER(MarlEnvParams), C.POINTER(MarlEnvState), C.c_uint64, C.c_uint64,
                                   _pd, C.c_void_p]),
 }

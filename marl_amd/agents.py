@@ -348,11 +348,30 @@ class TrainPacker:
                 pos += q.numel()
         if pos >= 1 << 24:
             raise ValueError("too many parameters for float32 positions")
-        self.gather = pack_train_weights(a2, c2).round().long()
-        self.flat = torch.zeros(pos, dtype=torch.float32, device=self.gather.device)
+        # positions counted from 1 in the parameter vector (marl_ppo_apply's `gather`); self.flat holds that vector from
+        # element 4 on (16-byte aligned, padded to whole groups of four), behind the zero that the padding entries read
+        at = pack_train_weights(a2, c2).round().long()
+        self.n = pos - 1
+        self.gather32 = at.to(torch.int32)
+        self.gather = torch.where(at > 0, at + 3, at)
+        self.flat = torch.zeros(4 + 4 * ((self.n + 3) // 4), dtype=torch.float32, device=at.device)
+        self.in_place = False
+
+    def adopt(self):
+        """Moves the parameters INTO the flat vector (every .data becomes a view of it): no copy per pack, and an
+        optimiser that works on the flat vector updates the modules."""
+        o = 4
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat[o:o + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat[o:o + k].view_as(p)
+                o += k
+        self.in_place = True
 
     def pack(self) -> torch.Tensor:
-        torch.cat([p.detach().reshape(-1) for p in self.params], out=self.flat[1:])
+        if not self.in_place:
+            torch.cat([p.detach().reshape(-1) for p in self.params], out=self.flat[4:4 + self.n])
         return self.flat[self.gather]
 
 
@@ -592,8 +611,16 @@ class PPOAgent:
             n = _lib.load().marl_ppo_weight_count(H)
             if n != packer.gather.numel():
                 raise _lib.MarlError(f"packed training weights: {packer.gather.numel()} floats, the library expects {n}")
-            self._fz = {"B": 0, "packer": packer, "stats": torch.zeros(5, dtype=torch.float64, device=self.device)}
+            # stats: row 0 for minibatches of batch_size rows, row 1 for the short one at the end of an epoch
+            self._fz = {"B": 0, "packer": packer, "stats": torch.zeros(2, 5, dtype=torch.float64, device=self.device)}
             self._fz["gindex"], self._fz["gflat"] = self._gradient_layout()
+            packer.adopt()
+            nflat = packer.flat.numel() - 4                     # whole groups of four, as marl_ppo_apply reads them
+            self._fz.update(packed=torch.empty(n, dtype=torch.float32, device=self.device),
+                            m=torch.zeros(nflat, dtype=torch.float32, device=self.device),
+                            v=torch.zeros(nflat, dtype=torch.float32, device=self.device),
+                            steps=torch.zeros(len(packer.params), dtype=torch.float32, device=self.device))
+            self._flatten_optimizer_state()
         z = self._fz
         if z["B"] < B:
             f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=self.device)
@@ -605,6 +632,54 @@ class PPOAgent:
             if "partial" not in z:
                 z["partial"] = f(lib.marl_ppo_partial_rows(), lib.marl_ppo_partial_floats(H))
         return z
+
+    def _flatten_optimizer_state(self):
+        """Adam's moments and step counters of both optimisers as views of three flat vectors (in the order of the flat
+        parameter vector), whatever they hold so far copied in: marl_ppo_apply then steps both optimisers in one
+        launch while optimizer.state_dict() stays what the reference's checkpoint holds (ppo_agent.py:386-420)."""
+        z = self._fz
+        params = z["packer"].params
+        n_actor_tensors = len(list(self.actor.parameters()))
+        o = 0
+        with torch.no_grad():
+            for i, p in enumerate(params):
+                opt = self.actor_optimizer if i < n_actor_tensors else self.critic_optimizer
+                st, k = opt.state[p], p.numel()
+                m, v, step = z["m"][o:o + k].view_as(p), z["v"][o:o + k].view_as(p), z["steps"][i]
+                if "exp_avg" in st:
+                    m.copy_(st["exp_avg"])
+                    v.copy_(st["exp_avg_sq"])
+                    step.copy_(torch.as_tensor(st["step"], dtype=torch.float32))
+                else:
+                    m.zero_()
+                    v.zero_()
+                    step.zero_()
+                st["step"], st["exp_avg"], st["exp_avg_sq"] = step, m, v
+                o += k
+        a = _lib.MarlPpoApply()
+        a.params, a.grads = z["packer"].flat[4:].data_ptr(), z["gflat"].data_ptr()
+        a.exp_avg, a.exp_avg_sq, a.steps = z["m"].data_ptr(), z["v"].data_ptr(), z["steps"].data_ptr()
+        ga, gc = self.actor_optimizer.param_groups[0], self.critic_optimizer.param_groups[0]
+        for g in (ga, gc):
+            if g["betas"] != ga["betas"] or g["eps"] != ga["eps"] or g["weight_decay"] != 0 or g["amsgrad"] or g["maximize"]:
+                raise _lib.MarlError("marl_ppo_apply: both optimisers must be plain Adam with the same betas and eps")
+        a.lr_actor, a.lr_critic = ga["lr"].data_ptr(), gc["lr"].data_ptr()
+        a.gather, a.packed, a.n_packed = z["packer"].gather32.data_ptr(), z["packed"].data_ptr(), z["packed"].numel()
+        a.n_actor = sum(p.numel() for p in self.actor.parameters())
+        a.n_critic = sum(p.numel() for p in self.critic.parameters())
+        a.tensors_actor, a.tensors_critic = n_actor_tensors, len(params) - n_actor_tensors
+        a.beta1, a.beta2, a.eps = float(ga["betas"][0]), float(ga["betas"][1]), float(ga["eps"])
+        a.max_norm, a.grad_scale = float(self.max_grad_norm), 1.0
+        z["apply"] = a
+
+    def _fused_apply(self, grad_scale: float = 1.0):
+        """Clip and both Adam steps (ppo_agent.py:324-325, 330-331) on the flat vectors, then the weights laid out
+        for the next row pass: marl_ppo_apply."""
+        a = self._fz["apply"]
+        a.grad_scale = float(grad_scale)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().marl_ppo_apply(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "marl_ppo_apply")
 
     def _gradient_layout(self):
         """Where every parameter gradient sits in what marl_ppo_products / marl_ppo_rows leave behind (include/marl_env.h):
@@ -634,28 +709,32 @@ class PPOAgent:
                  n[4].weight: c3[0:1], n[4].bias: chb[0:1, 5]}
         params = list(self.actor.parameters()) + list(self.critic.parameters())
         index = torch.cat([where[p].reshape(-1) for p in params]).to(torch.int32).to(self.device)
-        flat = torch.zeros(index.numel(), dtype=torch.float32, device=self.device)
+        # padded to whole groups of four floats (marl_ppo_apply reads it that way); the padding stays zero
+        flat = torch.zeros(4 * ((index.numel() + 3) // 4), dtype=torch.float32, device=self.device)[:index.numel()]
         o = 0
         for p in params:
             p.grad = flat[o:o + p.numel()].view_as(p)
             o += p.numel()
         return index, flat
 
-    def _fused_forward_backward(self, obs, actions, old_log_probs, advantages, returns, idx) -> torch.Tensor:
+    def _fused_forward_backward(self, obs, actions, old_log_probs, advantages, returns, idx, stats_row=None):
         """_forward_backward for the rows `idx` of the flat rollout tensors, without gathering them: one marl_ppo_rows
         launch (ppo_agent.py:296-323 per row, on the matrix cores), then every parameter gradient as the product of
-        two of the matrices it wrote.  Leaves the gradients in .grad, returns the five statistics."""
+        two of the matrices it wrote.  Leaves the gradients in .grad.  A call of its own (stats_row None) lays out
+        the current weights first and returns the five statistics; inside optimise() the weights are those
+        marl_ppo_apply left, and the sums over the rows are ADDED to row stats_row of the statistics (nothing returned)."""
         B, H = int(idx.numel()), self.hidden_dim
         z = self._fused_scratch(B)
-        z["stats"].zero_()
-        weights = z["packer"].pack()
+        if stats_row is None:
+            z["stats"][0].zero_()
+            z["packed"].copy_(z["packer"].pack())
         io = _lib.MarlPpoIO()
-        io.weights = weights.data_ptr()
+        io.weights = z["packed"].data_ptr()
         io.obs, io.actions, io.old_log_probs = obs.data_ptr(), actions.data_ptr(), old_log_probs.data_ptr()
         io.advantages, io.returns, io.index = advantages.data_ptr(), returns.data_ptr(), idx.data_ptr()
         for k in ("xe", "y1e", "y2e", "dz1", "dz2", "actor_sums", "dh", "cy1e", "cy2e", "cdz1", "cdz2", "dv"):
             setattr(io, k, z[k].data_ptr())
-        io.stats = z["stats"].data_ptr()
+        io.stats = z["stats"][stats_row or 0].data_ptr()
         io.clip_eps, io.c1, io.c2, io.v_max = float(self.clip_eps), float(self.c1), float(self.c2), float(self.v_max)
         io.log_std_min, io.log_std_max = float(self.actor.log_std_min), float(self.actor.log_std_max)
         with torch.cuda.device(self.device):
@@ -668,8 +747,8 @@ class PPOAgent:
             # per-workgroup slabs and per-wave rows -> the flat gradient vector every .grad is a view of
             _lib.check(lib.marl_ppo_reduce(z["gindex"].numel(), z["gindex"].data_ptr(), H, z["partial"].data_ptr(),
                                            z["actor_sums"].data_ptr(), z["gflat"].data_ptr(), st), "marl_ppo_reduce")
-        self._keep = (weights, idx)                       # the launch reads them after this call returns
-        return z["stats"] / B
+        self._keep = idx                                  # the launches read it after this call returns
+        return z["stats"][0] / B if stats_row is None else None
 
     def _apply_gradients(self):
         """Gradient-norm clip and both Adam steps (ppo_agent.py:324-325, 330-331)."""
@@ -724,6 +803,16 @@ class PPOAgent:
         keys = ("actor_loss", "critic_loss", "entropy", "clip_fraction", "approx_kl")
         acc = torch.zeros(len(keys), dtype=torch.float64, device=obs.device)
         steps = 0
+        if self.fused_update:
+            # the library adds every minibatch's sums over its rows to one of two rows of statistics (full minibatches,
+            # the short last one): sum(rows) / B per minibatch, summed over the steps so far, is their weighted sum
+            z = self._fused_scratch(min(n, self.batch_size))
+            z["stats"].zero_()
+            z["packed"].copy_(z["packer"].pack())
+            tail = n % self.batch_size
+            weight = torch.tensor([1.0 / min(n, self.batch_size), 1.0 / tail if tail and n > self.batch_size else 0.0],
+                                  dtype=torch.float64, device=obs.device)
+            world = torch.distributed.get_world_size() if _dist_on() else 1
         for epoch in range(self.n_epochs):
             if permutations is not None:
                 perm = torch.as_tensor(np.asarray(permutations[epoch]), dtype=torch.long, device=obs.device)
@@ -734,13 +823,11 @@ class PPOAgent:
             for s in range(0, n, self.batch_size):
                 idx = perm[s:s + self.batch_size]
                 if self.fused_update:
-                    out = self._fused_forward_backward(obs, actions, old_log_probs, advantages, returns, idx)
-                    if _dist_on() and torch.distributed.get_world_size() > 1:      # the gradients already are one flat vector
-                        torch.distributed.all_reduce(self._fz["gflat"])
-                        self._fz["gflat"].div_(torch.distributed.get_world_size())
-                    self._apply_gradients()
-                    acc += out
-                    epoch_kl += out[4]
+                    self._fused_forward_backward(obs, actions, old_log_probs, advantages, returns, idx,
+                                                 stats_row=0 if idx.numel() == min(n, self.batch_size) else 1)
+                    if world > 1:                                  # the gradients already are one flat vector
+                        torch.distributed.all_reduce(z["gflat"])
+                    self._fused_apply(1.0 / world)
                     nb += 1
                     steps += 1
                     continue
@@ -756,6 +843,10 @@ class PPOAgent:
                 epoch_kl += out[4]
                 nb += 1
                 steps += 1
+            if self.fused_update:
+                total = (z["stats"] * weight[:, None]).sum(0)
+                epoch_kl = total[4] - acc[4]
+                acc = total
             avg_kl = epoch_kl / max(nb, 1)
             if _dist_on():
                 torch.distributed.all_reduce(avg_kl)
@@ -840,6 +931,8 @@ class PPOAgent:
         self.training_stats = {k: [float(x) for x in v] for k, v in ck["training_stats"].items()}
         if "c2" in ck.get("config", {}):               # the decayed entropy weight is part of a resumed run's state
             self.set_entropy_coef(float(ck["config"]["c2"]))
+        if self._fz is not None:                       # the loaded moments into the flat vectors marl_ppo_apply steps
+            self._flatten_optimizer_state()
         # a captured step reads the tensors it was captured with: capture again after a load
         self._step_graph, self._step_static = None, None
         self._eager_steps = 0

@@ -652,6 +652,88 @@ __global__ __launch_bounds__(1024) void ppo_reduce_kernel(int n_out, const int32
     }
 }
 
+// Gradient-norm clip and Adam for both networks on the flat vectors (36 k parameters: the work is a few
+// microseconds; what it replaces is some thirty launches of a few microseconds each).  Element i < n_actor belongs
+// to the actor.  Every workgroup sums the squares of ALL gradients for itself (no exchange between workgroups, and
+// the same order of addition in each), then steps its own 4 096 elements.  Arithmetic of
+// torch.nn.utils.clip_grad_norm_ and of torch.optim.Adam's default settings (no weight decay, no amsgrad).
+constexpr int APPLY_THREADS = 1024;
+constexpr int APPLY_MAX_SWEEPS = 16;         // 16 x 4 096 parameters at most
+
+__global__ __launch_bounds__(APPLY_THREADS) void ppo_apply_kernel(MarlPpoApply a, int sweeps) {
+    typedef float floatx4 __attribute__((ext_vector_type(4)));
+    __shared__ float part[2][APPLY_THREADS / WAVE];
+    const int t = threadIdx.x;
+    const int n = a.n_actor + a.n_critic, n4 = (n + 3) / 4;
+    const floatx4* __restrict__ g4 = (const floatx4*)a.grads;
+    float sa = 0.0f, sc = 0.0f;
+    {
+        floatx4 g[APPLY_MAX_SWEEPS];
+#pragma unroll
+        for (int k = 0; k < APPLY_MAX_SWEEPS; ++k)
+            if (k < sweeps) { const int q = k * APPLY_THREADS + t; g[k] = g4[q < n4 ? q : n4 - 1]; }
+#pragma unroll
+        for (int k = 0; k < APPLY_MAX_SWEEPS; ++k)
+            if (k < sweeps) {
+                const int q = k * APPLY_THREADS + t;
+                if (q < n4) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float x = g[k][c] * a.grad_scale;           // the padding behind element n - 1 holds zeros
+                        if (4 * q + c < a.n_actor) sa += x * x; else sc += x * x;
+                    }
+                }
+            }
+    }
+    sa = wave_total(sa);
+    sc = wave_total(sc);
+    if ((t & (WAVE - 1)) == 0) { part[0][t / WAVE] = sa; part[1][t / WAVE] = sc; }
+    const double step_a = (double)a.steps[0] + 1.0, step_c = (double)a.steps[a.tensors_actor] + 1.0;
+    const float lr_a = *a.lr_actor, lr_c = *a.lr_critic;
+    __syncthreads();
+    sa = 0.0f; sc = 0.0f;
+#pragma unroll
+    for (int w = 0; w < APPLY_THREADS / WAVE; ++w) { sa += part[0][w]; sc += part[1][w]; }
+    const float clip_a = fminf(a.max_norm / (sqrtf(sa) + 1e-6f), 1.0f) * a.grad_scale;
+    const float clip_c = fminf(a.max_norm / (sqrtf(sc) + 1e-6f), 1.0f) * a.grad_scale;
+    // torch's kernel takes betas, eps and the learning rate as doubles and lets them promote every expression they
+    // enter; the bias corrections and the square root are single precision there
+    const float corr1_a = (float)(1.0 - pow(a.beta1, step_a)), corr1_c = (float)(1.0 - pow(a.beta1, step_c));
+    const double size_a = (double)lr_a / (double)corr1_a, size_c = (double)lr_c / (double)corr1_c;
+    const float root_a = sqrtf((float)(1.0 - pow(a.beta2, step_a))), root_c = sqrtf((float)(1.0 - pow(a.beta2, step_c)));
+    const int q = blockIdx.x * APPLY_THREADS + t;
+    if (q >= n4) return;
+    floatx4* __restrict__ m4 = (floatx4*)a.exp_avg;
+    floatx4* __restrict__ v4 = (floatx4*)a.exp_avg_sq;
+    floatx4* __restrict__ p4 = (floatx4*)a.params;
+    const floatx4 g = g4[q];
+    floatx4 m = m4[q], v = v4[q], p = p4[q];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bool actor = 4 * q + c < a.n_actor;
+        const float x = g[c] * (actor ? clip_a : clip_c);
+        m[c] = (float)((double)m[c] + (1.0 - a.beta1) * ((double)x - (double)m[c]));
+        v[c] = (float)(a.beta2 * (double)v[c] + (1.0 - a.beta2) * (double)x * (double)x);
+        const double denom = (double)(sqrtf(v[c]) / (actor ? root_a : root_c)) + a.eps;
+        p[c] = (float)((double)p[c] - (actor ? size_a : size_c) * (double)m[c] / denom);
+    }
+    m4[q] = m;
+    v4[q] = v;
+    p4[q] = p;
+}
+
+// After the step: the counters (every workgroup of the step kernel reads them, so they are advanced here), and
+// packed[j] = 0 where gather[j] == 0, else params[gather[j] - 1]: the weights in the order the row pass reads them.
+__global__ __launch_bounds__(256) void ppo_pack_kernel(int n, const int32_t* __restrict__ gather, const float* __restrict__ params,
+                                                       float* __restrict__ packed, float* __restrict__ steps, int n_steps) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n_steps) steps[j] += 1.0f;
+    if (j < n) {
+        const int k = gather[j];
+        packed[j] = k > 0 ? params[k - 1] : 0.0f;
+    }
+}
+
 int g_ppo_cus = 0;
 
 }  // namespace
@@ -728,6 +810,29 @@ int marl_ppo_reduce(int32_t n_out, const int32_t* index, int32_t hidden, const f
     if (slab == 0) return MARL_EUNSUPPORTED;
     hipLaunchKernelGGL(ppo_reduce_kernel, dim3((n_out + 31) / 32), dim3(32, 32), 0, (hipStream_t)stream, (int)n_out, index, partial,
                        (int)marl_ppo_partial_rows(), slab, actor_sums, (int)marl_ppo_sum_rows(), 4 * (int)hidden, out);
+    const hipError_t err = hipGetLastError();
+    if (err == hipSuccess) return MARL_OK;
+    marl_note_hip_error((int)err);
+    return MARL_EHIP;
+}
+
+int marl_ppo_apply(const MarlPpoApply* a, void* stream) {
+    if (a == nullptr || a->params == nullptr || a->grads == nullptr || a->exp_avg == nullptr || a->exp_avg_sq == nullptr ||
+        a->steps == nullptr || a->lr_actor == nullptr || a->lr_critic == nullptr)
+        return MARL_EINVAL;
+    if (((uintptr_t)a->params | (uintptr_t)a->grads | (uintptr_t)a->exp_avg | (uintptr_t)a->exp_avg_sq) & 15) return MARL_EINVAL;
+    if (a->n_actor < 1 || a->n_critic < 1 || a->tensors_actor < 1 || a->tensors_critic < 1 ||
+        a->tensors_actor + a->tensors_critic > APPLY_THREADS || a->n_packed < 0 ||
+        (a->n_packed > 0 && (a->gather == nullptr || a->packed == nullptr)))
+        return MARL_EINVAL;
+    const int n4 = (a->n_actor + a->n_critic + 3) / 4;
+    const int sweeps = (n4 + APPLY_THREADS - 1) / APPLY_THREADS;
+    if (sweeps > APPLY_MAX_SWEEPS) return MARL_EUNSUPPORTED;
+    hipLaunchKernelGGL(ppo_apply_kernel, dim3(sweeps), dim3(APPLY_THREADS), 0, (hipStream_t)stream, *a, sweeps);
+    const int n_steps = a->tensors_actor + a->tensors_critic;
+    const int most = a->n_packed > n_steps ? a->n_packed : n_steps;
+    hipLaunchKernelGGL(ppo_pack_kernel, dim3((most + 255) / 256), dim3(256), 0, (hipStream_t)stream, (int)a->n_packed, a->gather,
+                       (const float*)a->params, a->packed, a->steps, n_steps);
     const hipError_t err = hipGetLastError();
     if (err == hipSuccess) return MARL_OK;
     marl_note_hip_error((int)err);

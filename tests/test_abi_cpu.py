@@ -33,6 +33,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.MarlPolicyIO) == 9 * 8
     assert C.sizeof(_lib.MarlResetIO) == 11 * 8
     assert C.sizeof(_lib.MarlPpoIO) == 20 * 8 + 6 * 4
+    assert C.sizeof(_lib.MarlPpoApply) == 9 * 8 + 3 * 8 + 8 * 4  # 7 x 4 bytes, padded
 
 
 @pytest.mark.parametrize("cfg", [EnvConfig.fast_preset(), EnvConfig(),

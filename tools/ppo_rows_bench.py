@@ -30,17 +30,18 @@ def timed(f, reps=10):
 
 
 print("fused forward/backward  %.3f ms" % timed(lambda: agent._fused_forward_backward(obs, act, old, adv, ret, idx)))
-print("  + sync, clip, Adam    %.3f ms" % timed(lambda: (agent._fused_forward_backward(obs, act, old, adv, ret, idx), agent._sync.sync(), agent._apply_gradients())))
+print("  + torch clip, Adam    %.3f ms" % timed(lambda: (agent._fused_forward_backward(obs, act, old, adv, ret, idx), agent._apply_gradients())))
+print("step as in optimise()   %.3f ms" % timed(lambda: (agent._fused_forward_backward(obs, act, old, adv, ret, idx, stats_row=0), agent._fused_apply()), reps=40))
 z = agent._fz
 import ctypes as C
 from marl_amd import _lib
-w = z["packer"].pack()
+w = z["packed"]
 io = _lib.MarlPpoIO()
 io.weights = w.data_ptr(); io.obs, io.actions, io.old_log_probs = obs.data_ptr(), act.data_ptr(), old.data_ptr()
 io.advantages, io.returns, io.index = adv.data_ptr(), ret.data_ptr(), idx.data_ptr()
 for k in ("xe", "y1e", "y2e", "dz1", "dz2", "actor_sums", "dh", "cy1e", "cy2e", "cdz1", "cdz2", "dv"):
     setattr(io, k, z[k].data_ptr())
-io.stats = z["stats"].data_ptr()
+io.stats = z["stats"][0].data_ptr()
 io.clip_eps, io.c1, io.c2, io.v_max, io.log_std_min, io.log_std_max = 0.2, 0.5, 0.01, 5.0, -1.0, 0.5
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 print("marl_ppo_rows alone     %.3f ms" % timed(lambda: _lib.check(_lib.load().marl_ppo_rows(B, 128, C.byref(io), st))))
