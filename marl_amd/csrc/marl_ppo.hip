@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "marl_env.h"
 #include "marl_net.h"
@@ -475,9 +476,10 @@ __global__ __launch_bounds__((ROWS_THREADS<H, ACTOR>)) void ppo_rows_kernel(Marl
 // of the eight big arrays in with 16-byte loads (the tile-major layout makes them contiguous), one tile ahead in
 // registers, and lay it down in LDS row by row; there the operand of a contraction over rows is a plain 4-byte
 // read: step s takes rows 2 s and 2 s + 1, lane l the element of row 2 s + l / 32 in column 32 block + l % 32.
-// Waves 0..3 take the actor's products (wave w: row block w of dz2^T y1 and of dz1^T xe, column block w of
-// dh^T y2), waves 4..7 the critic's; every workgroup leaves its partial 32 x 32 blocks in `partial`, summed by
-// the caller (fixed order: deterministic).
+// One workgroup of four waves per network and CU (even workgroups: the actor's products, odd ones: the critic's;
+// wave w: row block w of dz2^T y1 and of dz1^T xe, column block w of dh^T y2).  Two workgroups share a CU and run out
+// of step with each other, so that one has its loads in flight while the other moves its tile into LDS.  Every pair
+// leaves its partial 32 x 32 blocks in one slab of `partial`, summed by the caller (fixed order: deterministic).
 template <int H>
 struct ProductLayout {
     static constexpr int NBO = H / 32;
@@ -490,8 +492,9 @@ struct ProductLayout {
     static constexpr int total = 2 * half;
     static constexpr int LD = H + 4;                      // LDS row pitch (floats)
     static constexpr int ARR = 32 * LD;
-    static constexpr int lds_floats = 8 * ARR + 32 * 8 + 32 * 8 + 32;
+    static constexpr int lds_floats = 4 * ARR + 32 * 8 + 32 * 8;
 };
+constexpr int PRODUCT_THREADS = 256;
 
 __device__ __forceinline__ void store_block(const floatx16& c, float* __restrict__ out, int ldo, int lane) {
     const int j = lane & 31, hl = lane >> 5;
@@ -500,49 +503,50 @@ __device__ __forceinline__ void store_block(const floatx16& c, float* __restrict
 }
 
 template <int H>
-__global__ __launch_bounds__(PPO_THREADS) void ppo_products_kernel(MarlPpoIO io, int tiles, float* __restrict__ partial) {
+__global__ __launch_bounds__(PRODUCT_THREADS) void ppo_products_kernel(MarlPpoIO io, int tiles, float* __restrict__ partial) {
     using L = ProductLayout<H>;
-    constexpr int NBO = L::NBO, LD = L::LD, ARR = L::ARR, PER = H / 64;      // 16-byte pieces of a tile per thread and array
+    constexpr int NBO = L::NBO, LD = L::LD, ARR = L::ARR, PER = H / 32;      // 16-byte pieces of a tile per thread and array
     extern __shared__ __align__(16) float lds[];
-    float* lx = lds + 8 * ARR;
+    float* lx = lds + 4 * ARR;
     float* ldh = lx + 32 * 8;
-    float* ldv = ldh + 32 * 8;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kh = lane >> 5;
-    const bool critic = wave >= 4;
-    const int w = wave & 3;
-    const float* src[8] = {io.dz2, io.y1e, io.dz1, io.y2e, io.cdz2, io.cy1e, io.cdz1, io.cy2e};
+    const bool critic = blockIdx.x & 1;
+    const int pair = blockIdx.x >> 1, pairs = gridDim.x >> 1;
+    const float* src[4] = {critic ? io.cdz2 : io.dz2, critic ? io.cy1e : io.y1e, critic ? io.cdz1 : io.dz1, critic ? io.cy2e : io.y2e};
     typedef float floatx4 __attribute__((ext_vector_type(4)));      // (HIP's float4 is a union type: arrays of it stay in scratch)
-    floatx4 st[8][PER], sx = {0, 0, 0, 0};
-    float sdv = 0.0f;
+    floatx4 st[4][PER], sx = {0, 0, 0, 0};
     // (every index of st is a constant when the loops are expanded by static_for; a run-time loop index, even of a
     // fully unrollable loop, sends the array to scratch memory)
     auto fetch = [&](int tile) {
-        static_for<0, 8>([&](auto aa) {
+        static_for<0, 4>([&](auto aa) {
             constexpr int a = decltype(aa)::value;
             const floatx4* p = reinterpret_cast<const floatx4*>(src[a] + (size_t)tile * 32 * H);
             static_for<0, PER>([&](auto kk) {
                 constexpr int k = decltype(kk)::value;
-                st[a][k] = p[tid + PPO_THREADS * k];
+                st[a][k] = p[tid + PRODUCT_THREADS * k];
             });
         });
+        // the critic's only head gradient, dL/dV, takes the place of head 0 of eight (the others zero): one loop body
+        // serves both networks
         if (tid < 64) sx = reinterpret_cast<const floatx4*>(io.xe + (size_t)tile * 32 * 8)[tid];
-        else if (tid < 128) sx = reinterpret_cast<const floatx4*>(io.dh + (size_t)tile * 32 * 8)[tid - 64];
-        else if (tid < 160) sdv = io.dv[(size_t)tile * 32 + tid - 128];
+        else if (tid < 128) {
+            if (!critic) sx = reinterpret_cast<const floatx4*>(io.dh + (size_t)tile * 32 * 8)[tid - 64];
+            else if ((tid & 1) == 0) sx[0] = io.dv[(size_t)tile * 32 + ((tid - 64) >> 1)];
+        }
     };
     auto lay_down = [&]() {
-        static_for<0, 8>([&](auto aa) {
+        static_for<0, 4>([&](auto aa) {
             constexpr int a = decltype(aa)::value;
             static_for<0, PER>([&](auto kk) {
                 constexpr int k = decltype(kk)::value;
-                const int f = tid + PPO_THREADS * k;             // piece f of the tile = chunk f / 32 (units 4 c ..), row f % 32
+                const int f = tid + PRODUCT_THREADS * k;         // piece f of the tile = chunk f / 32 (units 4 c ..), row f % 32
                 *reinterpret_cast<floatx4*>(lds + a * ARR + (f & 31) * LD + 4 * (f >> 5)) = st[a][k];
             });
         });
         if (tid < 64) reinterpret_cast<floatx4*>(lx)[tid] = sx;
         else if (tid < 128) reinterpret_cast<floatx4*>(ldh)[tid - 64] = sx;
-        else if (tid < 160) ldv[tid - 128] = sdv;
     };
     // The big product runs on the matrix cores; the narrow ones (6 columns of xe, 8 heads, the bias sums) are a few
     // multiply-adds per step on the vector pipe beside them: lane (unit i of block w, row parity) keeps its own
@@ -550,46 +554,45 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_products_kernel(MarlPpoIO io,
     floatx16 acc2[NBO];
     float s1[6] = {}, sh[8] = {}, sb = 0.0f, shb = 0.0f;
     static_for<0, NBO>([&](auto cc) { acc2[decltype(cc)::value] = floatx16{0}; });
-    const float* A2 = lds + (critic ? 4 : 0) * ARR;
+    const float* A2 = lds;
     const float* Y1 = A2 + ARR;
     const float* A1 = A2 + 2 * ARR;
     const float* Y2 = A2 + 3 * ARR;
     const int col = 32 * w + i;
     const int i8 = i & 7;
-    int tile = blockIdx.x;
+    auto steps = [&]() {
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const int row = 2 * s + kh;
+            const float a2 = A2[row * LD + col], a1 = A1[row * LD + col], bh = Y2[row * LD + col];
+            const float4 xa = *reinterpret_cast<const float4*>(lx + row * 8), xb = *reinterpret_cast<const float4*>(lx + row * 8 + 4);
+            s1[0] = fmaf(a1, xa.x, s1[0]); s1[1] = fmaf(a1, xa.y, s1[1]); s1[2] = fmaf(a1, xa.z, s1[2]);
+            s1[3] = fmaf(a1, xa.w, s1[3]); s1[4] = fmaf(a1, xb.x, s1[4]); s1[5] = fmaf(a1, xb.y, s1[5]);
+            sb += a2;
+            const float4 ha = *reinterpret_cast<const float4*>(ldh + row * 8), hb = *reinterpret_cast<const float4*>(ldh + row * 8 + 4);
+            sh[0] = fmaf(ha.x, bh, sh[0]); sh[1] = fmaf(ha.y, bh, sh[1]); sh[2] = fmaf(ha.z, bh, sh[2]); sh[3] = fmaf(ha.w, bh, sh[3]);
+            sh[4] = fmaf(hb.x, bh, sh[4]); sh[5] = fmaf(hb.y, bh, sh[5]); sh[6] = fmaf(hb.z, bh, sh[6]); sh[7] = fmaf(hb.w, bh, sh[7]);
+            shb += ldh[row * 8 + i8];                        // lane i < 8: the sum of head i's gradients
+            static_for<0, NBO>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                acc2[c] = mfma(a2, Y1[row * LD + 32 * c + i], acc2[c]);
+            });
+        }
+    };
+    int tile = pair;
     if (tile < tiles) fetch(tile);
-    for (; tile < tiles; tile += gridDim.x) {
+    for (; tile < tiles; tile += pairs) {
         __syncthreads();                                   // the tile before has been consumed
         lay_down();
         __syncthreads();
-        if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
-        if (w < NBO) {
-#pragma unroll 4
-            for (int s = 0; s < 16; ++s) {
-                const int row = 2 * s + kh;
-                const float a2 = A2[row * LD + col], a1 = A1[row * LD + col], bh = Y2[row * LD + col];
-                const float4 xa = *reinterpret_cast<const float4*>(lx + row * 8), xb = *reinterpret_cast<const float4*>(lx + row * 8 + 4);
-                s1[0] = fmaf(a1, xa.x, s1[0]); s1[1] = fmaf(a1, xa.y, s1[1]); s1[2] = fmaf(a1, xa.z, s1[2]);
-                s1[3] = fmaf(a1, xa.w, s1[3]); s1[4] = fmaf(a1, xb.x, s1[4]); s1[5] = fmaf(a1, xb.y, s1[5]);
-                sb += a2;
-                if (critic) {
-                    const float dv = ldv[row];
-                    sh[0] = fmaf(dv, bh, sh[0]);
-                    shb += dv;
-                } else {
-                    const float4 ha = *reinterpret_cast<const float4*>(ldh + row * 8), hb = *reinterpret_cast<const float4*>(ldh + row * 8 + 4);
-                    sh[0] = fmaf(ha.x, bh, sh[0]); sh[1] = fmaf(ha.y, bh, sh[1]); sh[2] = fmaf(ha.z, bh, sh[2]); sh[3] = fmaf(ha.w, bh, sh[3]);
-                    sh[4] = fmaf(hb.x, bh, sh[4]); sh[5] = fmaf(hb.y, bh, sh[5]); sh[6] = fmaf(hb.z, bh, sh[6]); sh[7] = fmaf(hb.w, bh, sh[7]);
-                    shb += ldh[row * 8 + i8];                    // lane i < 8: the sum of head i's gradients
-                }
-                static_for<0, NBO>([&](auto cc) {
-                    constexpr int c = decltype(cc)::value;
-                    acc2[c] = mfma(a2, Y1[row * LD + 32 * c + i], acc2[c]);
-                });
-            }
-        }
+#ifndef PRODUCT_SKIP_FETCH
+        if (tile + pairs < tiles) fetch(tile + pairs);
+#endif
+#ifndef PRODUCT_SKIP_STEPS
+        if (w < NBO) steps();
+#endif
     }
-    float* out = partial + (size_t)blockIdx.x * L::total + (critic ? L::half : 0);
+    float* out = partial + (size_t)pair * L::total + (critic ? L::half : 0);
     if (w < NBO) {
         static_for<0, NBO>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
@@ -779,7 +782,7 @@ int marl_ppo_products(int32_t B, int32_t hidden, const MarlPpoIO* io, float* par
         io->dh == nullptr || io->cy1e == nullptr || io->cy2e == nullptr || io->cdz1 == nullptr || io->cdz2 == nullptr ||
         io->dv == nullptr)
         return MARL_EINVAL;
-    const int grid = ppo_cus();                 // every workgroup writes its partial blocks (zeros if it has no tile)
+    const int grid = 2 * ppo_cus();             // every workgroup writes its partial blocks (zeros if it has no tile)
     const int tiles = (B + 31) / 32;
     hipError_t err = hipSuccess;
 #define MARL_LAUNCH_PRODUCTS(HH)                                                                                     \
@@ -792,7 +795,7 @@ int marl_ppo_products(int32_t B, int32_t hidden, const MarlPpoIO* io, float* par
             attr_set = err == hipSuccess;                                                                             \
         }                                                                                                             \
         if (err == hipSuccess)                                                                                        \
-            hipLaunchKernelGGL(ppo_products_kernel<HH>, dim3(grid), dim3(PPO_THREADS), lds_bytes, (hipStream_t)stream, \
+            hipLaunchKernelGGL(ppo_products_kernel<HH>, dim3(grid), dim3(PRODUCT_THREADS), lds_bytes, (hipStream_t)stream, \
                                *io, tiles, partial);                                                                  \
     } while (0)
     if (hidden == 64) MARL_LAUNCH_PRODUCTS(64); else MARL_LAUNCH_PRODUCTS(128);

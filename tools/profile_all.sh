@@ -5,11 +5,12 @@
 # command (three streams).  Summaries land under gpurun_out/profiles_<tag>/; copy what is to be kept into profiles/.
 set -o pipefail
 tag=${1:-r02}
+configs=${2:-"3 2 4 5"}        # e.g. tools/profile_all.sh r02f 5
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/profiles_$tag
 mkdir -p $out
 db() { ls -t $1/*/*.db $1/*.db 2>/dev/null | head -1; }
-for c in 3 2 4 5; do
+for c in $configs; do
   case $c in 2) A="--steps 300 --warmup 50";; 3) A="--steps 100 --warmup 20";; 4) A="--steps 10 --warmup 2";; 5) A="--steps 64 --warmup 64";; esac
   B="python3 bench.py --config $c $A --no-cpu-baseline --shards 1"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${tag}_c$c -o r -- $B > $out/c${c}_trace_bench.json 2> $out/c${c}_trace.err || { echo "trace c$c failed"; tail -3 $out/c${c}_trace.err; exit 1; }
