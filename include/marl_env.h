@@ -45,6 +45,7 @@ extern "C" {
 #define MARL_OBS_DIM 5
 #define MARL_ASSIGN_NONE (-2)
 #define MARL_MAX_N 256          /* enemies per env supported by the kernels */
+#define MARL_MAX_N_LAMBDA2 1024 /* vertices per graph supported by marl_lambda2_from_bits alone */
 #define MARL_MAX_M 64           /* jammers per env */
 #define MARL_ENEMY_RANDOM_WALK 0        /* EnemySwarm._step_random_walk, enemy_swarm.py:157-189 */
 #define MARL_ENEMY_COORDINATED_TURN 1   /* EnemySwarm._step_coordinated_turn, enemy_swarm.py:191-242 */
@@ -233,12 +234,14 @@ int marl_jam_mask_bits(const MarlEnvParams *p, int32_t E, const double *x, const
                        const int32_t *jam_band, uint32_t *bits, void *stream);
 
 /* compute_laplacian + compute_lambda2 (physics/communication_graph.py:184-286)
- * from adjacency bits [E][N][ceil(N/32)] -> lambda2 [E]. */
+ * from adjacency bits [E][N][ceil(N/32)] -> lambda2 [E].  N <= MARL_MAX_N_LAMBDA2: beyond MARL_MAX_N -- the range
+ * of the reference's sparse branch (communication_graph.py:268-278, the same eigenvalue) -- a stand-alone solver,
+ * one workgroup per graph (Householder + Sturm multisection, result within 1e-11 of LAPACK's; `rounds` unused). */
 int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t *bits, double *lambda2,
                            int32_t rounds, void *workspace, void *stream);
 
-/* Bytes of device scratch marl_lambda2_from_bits needs (0 for N <= 64; the matrix of the
- * eigenproblem otherwise).  marl_state_bytes already includes the same amount for the step. */
+/* Bytes of device scratch marl_lambda2_from_bits needs (0 for N <= 64 and for N > MARL_MAX_N_LAMBDA2; the matrix
+ * of the eigenproblem otherwise).  marl_state_bytes already includes the same amount for the step. */
 size_t marl_lambda2_workspace_bytes(int32_t N, int32_t E);
 
 /* The same as marl_lambda2_from_bits without a workspace argument and without any allocation.  It has no

@@ -2926,6 +2926,10 @@ size_t workspace_bytes(int N, int E) {
 // ====================================================================== C ABI
 // for the other translation units of the library: what marl_last_hip_error reports
 extern "C" __attribute__((visibility("hidden"))) void marl_note_hip_error(int err) { g_last_hip_error = err; }
+// marl_lambda2_large.hip: the solver for graphs beyond MARL_MAX_N vertices (returns a hipError_t)
+extern "C" __attribute__((visibility("hidden"))) int marl_lambda2_large_ld(int n);
+extern "C" __attribute__((visibility("hidden"))) int marl_lambda2_large_launch(int n, int E, const uint32_t* bits, double* lambda2,
+                                                                              double* workspace, void* stream);
 
 extern "C" {
 
@@ -3205,14 +3209,22 @@ int marl_jam_mask_bits(const MarlEnvParams* p, int32_t E, const double* x, const
 }
 
 size_t marl_lambda2_workspace_bytes(int32_t N, int32_t E) {
-    if (N < 1 || N > MARL_MAX_N || E < 1) return 0;
+    if (N < 1 || N > MARL_MAX_N_LAMBDA2 || E < 1) return 0;
+    if (N > MARL_MAX_N) {
+        const size_t ld = (size_t)marl_lambda2_large_ld(N);
+        return (size_t)E * ld * ld * sizeof(double);
+    }
     return workspace_bytes(N, E);
 }
 
 int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t* bits, double* lambda2, int32_t rounds,
                            void* workspace, void* stream) {
     if (N < 1 || E < 1 || !bits || !lambda2) return MARL_EINVAL;
-    if (N > MARL_MAX_N) return MARL_EUNSUPPORTED;
+    if (N > MARL_MAX_N_LAMBDA2) return MARL_EUNSUPPORTED;
+    if (N > MARL_MAX_N) {                          // the stand-alone solver for large graphs (marl_lambda2_large.hip)
+        if (workspace == nullptr) return MARL_EINVAL;
+        return hip_check((hipError_t)marl_lambda2_large_launch(N, E, bits, lambda2, (double*)workspace, stream));
+    }
     if (rounds <= 0) rounds = 8;
     if (N > WAVE) {
         if (workspace == nullptr) return MARL_EINVAL;

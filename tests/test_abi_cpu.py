@@ -88,6 +88,7 @@ def test_state_carving_is_disjoint_and_aligned():
     p2 = EnvConfig.fast_preset(N=200, M=16).to_params()
     n2 = lib.marl_state_bytes(C.byref(p2), E)
     assert E * 200 * 200 * 8 <= lib.marl_lambda2_workspace_bytes(200, E) <= E * 200 * 200 * 8 + 4096 and n2 > E * 200 * 200 * 8
+    assert lib.marl_lambda2_workspace_bytes(1000, 2) == 2 * 1024 * 1024 * 8 and lib.marl_lambda2_workspace_bytes(1025, 1) == 0
     _lib.check(lib.marl_state_bind(C.byref(st), C.byref(p2), E, C.c_void_p(base)))
     assert st.workspace is not None and st.workspace + E * 200 * 200 * 8 <= base + n2
     assert st.solve_rows is None                      # the three-launch step is for N <= 64

@@ -67,3 +67,45 @@ def test_env_step_op_mutates_registered_state():
         assert torch.equal(a.views["enemy_x"], b.views["enemy_x"])
     pa = torch.ops.marl_amd.reward_per_agent(b._buf, h, b.lambda2.clone())
     assert pa.shape == (32, 4) and torch.equal(pa, a.reward_per_agent())
+
+
+def _pack_bits(adj):
+    """bool [E,N,N] -> the int32 words [E,N,ceil(N/32)] of the adjacency-bit layout (bit k of word w: vertex 32 w + k)."""
+    E, N, _ = adj.shape
+    W = (N + 31) // 32
+    padded = np.zeros((E, N, 32 * W), dtype=np.uint8)
+    padded[:, :, :N] = adj
+    return np.packbits(padded.reshape(E, N, W, 32), axis=-1, bitorder="little").view(np.uint32).reshape(E, N, W)
+
+
+@pytest.mark.parametrize("N", [257, 300, 640, 1024])
+def test_lambda2_of_large_graphs_equals_lapack(N):
+    """compute_lambda2 beyond the env kernels' 256 vertices (communication_graph.py:219-286, the size range of its sparse
+    branch): sparse, dense, disconnected, complete and path graphs against numpy's eigvalsh.  The reference's own
+    fixtures stop at N = 200, so the expected values here are LAPACK's on the same Laplacian (its dense branch)."""
+    import marl_amd.ops  # noqa: F401
+    rng = np.random.RandomState(N)
+    adj = np.zeros((6, N, N), dtype=bool)
+    for e, p in enumerate((2.5 * np.log(N) / N, 0.3, 0.5 * np.log(N) / N)):      # connected sparse, dense, disconnected
+        upper = np.triu(rng.rand(N, N) < p, 1)
+        adj[e] = upper | upper.T
+    adj[3] = ~np.eye(N, dtype=bool)                                               # complete: lambda2 = N
+    i = np.arange(N - 1)
+    adj[4, i, i + 1] = adj[4, i + 1, i] = True                                    # path: already tridiagonal
+    adj[5, : N // 2, : N // 2] = ~np.eye(N // 2, dtype=bool)                      # a clique and isolated vertices
+    bits = torch.from_numpy(_pack_bits(adj).view(np.int32)).cuda()
+    got = torch.ops.marl_amd.lambda2_from_bits(bits, 0).cpu().numpy()
+    for e in range(adj.shape[0]):
+        a = adj[e].astype(np.float64)
+        want = np.linalg.eigvalsh(np.diag(a.sum(1)) - a)[1]
+        assert abs(got[e] - want) <= 1e-9 * max(1.0, abs(want)), (e, got[e], want)
+    assert abs(got[3] - N) < 1e-9 and abs(got[2]) < 1e-9 and abs(got[5]) < 1e-9
+
+
+def test_lambda2_size_limits():
+    from marl_amd import _lib
+    lib = _lib.load()
+    out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    bits = torch.zeros(1, 1025, 33, dtype=torch.int32, device="cuda")
+    assert lib.marl_lambda2_from_bits(1025, 1, bits.data_ptr(), out.data_ptr(), 0, None, None) == _lib.MARL_EUNSUPPORTED
+    assert lib.marl_lambda2_from_bits(300, 1, bits.data_ptr(), out.data_ptr(), 0, None, None) == _lib.MARL_EINVAL   # no workspace
