@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--shards", type=int, default=None,
                     help="parts of the batch stepped on HIP streams of their own (default: 3 for config 3, else 1)")
+    ap.add_argument("--schedule", default=os.environ.get("MARL_BENCH_SCHEDULE", "auto"),
+                    choices=["auto", "fused", "split"], help="EnvConfig.step_schedule (testing: A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
@@ -211,7 +213,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    cfg = EnvConfig.fast_preset(N=N_ENEMY, M=M_JAM, recluster=not cfgd["reward_only"])
+    cfg = EnvConfig.fast_preset(N=N_ENEMY, M=M_JAM, recluster=not cfgd["reward_only"],
+                                step_schedule=args.schedule)
     extra = {}
     if args.config == 5:
         from marl_amd.trainer import BatchedTrainer

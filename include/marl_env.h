@@ -55,6 +55,10 @@ extern "C" {
 #define MARL_STAGE_NO_RECLUSTER 1        /* marl_env_step leaves the K_recompute re-clustering (jammer_env.py:394-402) out:
                                            the cluster table of the last reset stays; with MarlStepIO.obs = NULL this is the
                                            "step + reward only" form of the step */
+#define MARL_STAGE_NO_SOLVE_PRIORITY 2    /* the split schedule's eigen-solves leave the wave priority alone (by default, for
+                                           batches that the chip holds in about one round of solve waves, a solve's issue
+                                           priority follows the work it has left, so that the solves of a SIMD finish together);
+                                           marl_env_step_parts sets it for its parts */
 
 enum {
     MARL_OK = 0,

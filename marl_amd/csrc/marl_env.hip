@@ -544,14 +544,69 @@ __device__ __forceinline__ double column_of(const double (&a)[NPAD], int i) {
     }
 }
 
+// Issue priority of the wave by the work it has left.  The SIMD's arbiter serves the oldest wave first, so of four
+// solves that start together the last one is held back until the others are done and then runs alone, at the pace
+// of its dependency chains (measured: a wave alone issues an instruction per 11 clocks, the SIMD has room for one
+// per 4).  With the priority following the remaining work the waves of a SIMD finish together and the pipe stays
+// full to the end.  Work left, in instructions: about 85 + 3 i per Householder step that reduces row i, then 4 per
+// term and round of the eigenvalue search; the four levels of the hardware are spaced more finely towards the end,
+// where the finishing order is decided.
+template <bool ON>
+struct SolvePriority {
+    int left, level, scale;       // scale: the work of the largest solve, the measure of the levels
+    static __device__ __forceinline__ void set(int lv) {
+        if (lv == 3) __builtin_amdgcn_s_setprio(3);
+        else if (lv == 2) __builtin_amdgcn_s_setprio(2);
+        else if (lv == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+    // instructions of a solve of np vertices, roughly: 85 + 3 i per Householder step that reduces row i, then 4 per
+    // term and round of the eigenvalue search
+    static __device__ __forceinline__ int work(int np, int rounds) {
+        const int i = np - 1;
+        return np < 2 ? 0 : 85 * i + (3 * i * i) / 2 + 4 * rounds * np;
+    }
+    // `total`: the work the wave has before it, this solve included (a wave of the per-CU launch knows its list);
+    // `top`: the work of the largest solve the launch can hold
+    __device__ __forceinline__ void start(int total, int top) {
+        if constexpr (ON) {
+            left = total;
+            scale = top > 16 ? top : 16;
+            level = 0;
+            spend(0);
+        }
+    }
+    // Levels at 45 %, 24 % and 11 % of the top: closer together towards the end, where the finishing order is decided.
+    // (Alternating between neighbouring levels from step to step, for a priority that follows the work continuously,
+    // slowed every wave down by half: priority changes are not free.)
+    __device__ __forceinline__ void spend(int cost) {
+        if constexpr (!ON) return;
+        left -= cost;
+        const int x = left * 100;
+        const int lv = x >= 45 * scale ? 3 : x >= 24 * scale ? 2 : x >= 11 * scale ? 1 : 0;
+        if (lv != level && (lv < level || cost == 0)) {      // rises only at the start
+            level = lv;
+            set(lv);
+        }
+    }
+    __device__ __forceinline__ void finish() {
+        if constexpr (ON) {
+            if (level != 0) __builtin_amdgcn_s_setprio(0);
+            level = 0;
+        }
+    }
+};
+
 // Sturm multisection for the largest eigenvalue of the symmetric tridiagonal matrix
 // (L.de[k] = (d_k, e_k^2), k < np) inside [lo, hi]: lane t evaluates the Sturm sequence
 // p_0 = 1, p_k = (d_k - x) p_{k-1} - e_k^2 p_{k-2} at x_t; its sign changes count the
 // eigenvalues below x_t.  Every round shrinks the bracket 65-fold.
-template <class LDS>
-__device__ __forceinline__ double sturm_largest_wave(const LDS& L, int np, int lane, double lo, double hi, int rounds) {
+template <class LDS, bool PRIO = false>
+__device__ __forceinline__ double sturm_largest_wave(const LDS& L, int np, int lane, double lo, double hi, int rounds,
+                                                     SolvePriority<PRIO>* prio = nullptr) {
     for (int r = 0; r < rounds; ++r) {
         if (hi - lo <= 1e-11 * hi) break;
+        if (prio) prio->spend(4 * np);
         const double w = (hi - lo) * (1.0 / 65.0);
         const double x = lo + w * (double)(lane + 1);
         // The signs of p_1, p_2, ... are shifted into a 32-bit register (one v_alignbit_b32 per term);
@@ -617,7 +672,7 @@ __device__ __forceinline__ double sturm_largest_wave(const LDS& L, int np, int l
 #else
 #define TSTAMP(k, pin)
 #endif
-template <int NPAD, class LDS>
+template <int NPAD, class LDS, bool PRIO = false>
 __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int lane, LDS& L, int rounds) {
     const int cdeg = __popcll(crow);
     int dmax = cdeg;
@@ -653,8 +708,11 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
 #endif
     // pivot column A[lane][i]: the first one from the bits, the later ones handed back by the update
     double col = (lane == np - 1) ? (double)cdeg : -(double)((crow >> (np - 1)) & 1ull);
+    SolvePriority<PRIO> prio;
+    prio.start(SolvePriority<PRIO>::work(np, rounds), SolvePriority<PRIO>::work(NPAD, rounds));
     for (int i = np - 1; i >= 2; --i) {
         const int l = i - 1;
+        prio.spend(85 + 3 * i);
         TSTAMP(0, col);
         const double aii = col;                            // meaningful in lane i: A[i][i]
         double uj = (lane <= l) ? col : 0.0;
@@ -704,7 +762,9 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
     WSYNC();
     const double lo = (double)(dmax + 1) * (1.0 - 1e-13) - 1e-13;
     const double hi = (double)min(np, 2 * dmax) * (1.0 + 1e-13) + 1e-13;
-    return sturm_largest_wave(L, np, lane, lo, hi, rounds);
+    const double mu = sturm_largest_wave<LDS, PRIO>(L, np, lane, lo, hi, rounds, &prio);
+    prio.finish();
+    return mu;
 }
 
 // ---- two eigenproblems per wave (n' <= 32 each) ----------------------------------------------------------
@@ -732,7 +792,7 @@ __device__ __forceinline__ double half_lane(double v, int src, bool upper) {   /
 
 // mu_max of both problems; `crow` = the lane's 32-bit complement row, np = max(n'_A, n'_B) <= 32, np_own = the
 // size of the lane's own problem (0: no problem in this half).  The result is valid in every lane of a half.
-template <class LDS>
+template <class LDS, bool PRIO = false>
 __device__ __forceinline__ double mu_max_pair_wave(uint32_t crow, int np, int np_own, int lane, LDS& L, int rounds) {
     constexpr int NPAD = 32, KB = 2;
     const bool upper = lane >= 32;
@@ -758,8 +818,11 @@ __device__ __forceinline__ double mu_max_pair_wave(uint32_t crow, int np, int np
         });
     }
     double col = (hl == np - 1) ? (double)cdeg : -(double)((crow >> (np - 1)) & 1u);
+    SolvePriority<PRIO> prio;
+    prio.start(SolvePriority<PRIO>::work(np, rounds), SolvePriority<PRIO>::work(NPAD, rounds));
     for (int i = np - 1; i >= 2; --i) {
         const int l = i - 1;
+        prio.spend(85 + 3 * i);
         const double aii = col;
         double uj = (hl <= l) ? col : 0.0;
         const double h = half_sum(uj * uj);
@@ -806,6 +869,7 @@ __device__ __forceinline__ double mu_max_pair_wave(uint32_t crow, int np, int np
     for (int r = 0; r < rounds; ++r) {
         const bool active = (hi - lo) > 1e-11 * hi;
         if (ballot64(active) == 0) break;
+        prio.spend(4 * np);
         const double w = (hi - lo) * (1.0 / 33.0);
         const double x = lo + w * (double)(hl + 1);
         double pm = 1.0, pc = de[0].x - x;
@@ -849,6 +913,7 @@ __device__ __forceinline__ double mu_max_pair_wave(uint32_t crow, int np, int np
             }
         }
     }
+    prio.finish();
     return 0.5 * (lo + hi);
 }
 
@@ -1426,23 +1491,41 @@ struct SolveLds {
     double2 de[WAVE];
 };
 
-// Solve: block b takes the b-th largest pending eigenproblem, then finishes that env's reward.
-template <int NPAD>
-__global__ __launch_bounds__(WAVE) void env_step_solve_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
-    __shared__ SolveLds L;
-    const int lane = threadIdx.x;
-    const int total = S.solve_hist[SOLVE_HIST_TOTAL];
-    // the problems of more than 32 vertices take a wave each (blocks 0..nbig-1), the others share one in pairs
-    const int nbig = S.solve_hist[SOLVE_HIST_TOTAL + 1];
-    const int npairs = (total - nbig + 1) >> 1;
-    if ((int)blockIdx.x >= nbig && (int)blockIdx.x < nbig + npairs) {
-        const int k = nbig + 2 * ((int)blockIdx.x - nbig);
+#ifdef MARL_EXP_BLOCKTIME
+// Timeline probe (tools/solve_timeline.py): in place of its env's reward terms a solve records the hardware id
+// of its wave, the size of its problem and its start / end clock.
+#define BT_BEGIN()                                                                                                \
+    uint32_t bt_hw, bt_xcc;                                                                                       \
+    uint64_t bt_t0, bt_t1;                                                                                        \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)\n\ts_memtime %2\n\ts_waitcnt lgkmcnt(0)" \
+                 : "=s"(bt_hw), "=s"(bt_xcc), "=s"(bt_t0)::"memory")
+#define BT_RECORD(env, npv, item)                                                                                 \
+    do {                                                                                                          \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bt_t1)::"memory"); \
+        uint32_t* w_ = reinterpret_cast<uint32_t*>(io.reward_terms + (size_t)(env) * 5);                          \
+        w_[0] = bt_hw; w_[1] = (bt_xcc & 0xF) | ((uint32_t)(npv) << 8) | 0xAB000000u;                             \
+        w_[2] = (uint32_t)bt_t0; w_[3] = (uint32_t)bt_t1; w_[4] = (uint32_t)(item);                               \
+    } while (0)
+#else
+#define BT_BEGIN()
+#define BT_RECORD(env, npv, item)
+#endif
+
+// Work item `item` of a step's solve launch, by one wave: the items are the pending eigenproblems in the order of
+// solve_perm (largest first).  The problems of more than 32 vertices are an item each (items 0..nbig-1), the others
+// share one in pairs.  The wave then finishes the reward of the env (or the two).
+template <int NPAD, bool PRIO>
+__device__ __forceinline__ void solve_item(const MarlEnvParams& P, const MarlEnvState& S, const MarlStepIO& io, int item,
+                                           int nbig, int total, int lane, SolveLds& L) {
+    BT_BEGIN();
+    if (item >= nbig) {
+        const int k = nbig + 2 * (item - nbig);
         const int eA = S.solve_perm[k], eB = (k + 1 < total) ? S.solve_perm[k + 1] : -1;
         const int npA = S.solve_np[eA], npB = (eB >= 0) ? S.solve_np[eB] : 0;      // sorted: npA >= npB
         const bool upper = lane >= 32;
         const int e = upper ? eB : eA, np_own = upper ? npB : npA, hl = lane & 31;
         const uint32_t crow = (e >= 0 && hl < np_own) ? (uint32_t)S.solve_rows[(size_t)e * WAVE + hl] : 0u;
-        const double mu = mu_max_pair_wave(crow, npA, np_own, lane, L, P.lambda2_rounds + 2);
+        const double mu = mu_max_pair_wave<SolveLds, PRIO>(crow, npA, np_own, lane, L, P.lambda2_rounds + 2);
         if (hl == 0 && e >= 0) {
             const double lam = (double)P.N - mu;
             const double* part = S.solve_partial + (size_t)e * 4;
@@ -1450,33 +1533,56 @@ __global__ __launch_bounds__(WAVE) void env_step_solve_kernel(MarlEnvParams P, M
             double r1;
             const double total_r = reward_total(P, lam, lam0, part[0], part[1], (float)part[2], part[3], r1);
             finish_env(P, S, io, e, S.step_count[e], total_r, lam, lam0);
-#ifndef MARL_EXP_TIMING
+#if !defined(MARL_EXP_TIMING) && !defined(MARL_EXP_BLOCKTIME)
             if (io.reward_terms) io.reward_terms[(size_t)e * 5] = (float)r1;
 #endif
+            BT_RECORD(e, np_own, item);
         }
         return;
     }
-    if ((int)blockIdx.x >= nbig + npairs) {
-        // the histogram has been consumed by the order kernel: the last block clears it for the next step
-        // (bins only: the other blocks of this launch still read the total)
-        if (blockIdx.x == gridDim.x - 1)
-            for (int k = lane; k < SOLVE_HIST_TOTAL; k += WAVE) S.solve_hist[k] = 0;
-        return;
-    }
-    const int e = S.solve_perm[blockIdx.x];
+    const int e = S.solve_perm[item];
     const int np = S.solve_np[e];
     const uint64_t crow = (lane < np) ? S.solve_rows[(size_t)e * WAVE + lane] : 0ull;
-    const double lam = (double)P.N - mu_max_compact_wave<NPAD>(crow, np, lane, L, P.lambda2_rounds);
+    const double lam = (double)P.N - mu_max_compact_wave<NPAD, SolveLds, PRIO>(crow, np, lane, L, P.lambda2_rounds);
     if (lane == 0) {
         const double* part = S.solve_partial + (size_t)e * 4;
         double r1;
         const double lam0 = S.lambda2_initial[e];
         const double total_r = reward_total(P, lam, lam0, part[0], part[1], (float)part[2], part[3], r1);
         finish_env(P, S, io, e, S.step_count[e], total_r, lam, lam0);
-#ifndef MARL_EXP_TIMING
+#if !defined(MARL_EXP_TIMING) && !defined(MARL_EXP_BLOCKTIME)
         if (io.reward_terms) io.reward_terms[(size_t)e * 5] = (float)r1;
 #endif
+        BT_RECORD(e, np, item);
     }
+}
+
+// Solve, one wave per workgroup: block b takes item b.
+template <int NPAD, bool PRIO>
+__device__ __forceinline__ void solve_block(const MarlEnvParams& P, const MarlEnvState& S, const MarlStepIO& io) {
+    __shared__ SolveLds L;
+    const int lane = threadIdx.x;
+    const int total = S.solve_hist[SOLVE_HIST_TOTAL];
+    const int nbig = S.solve_hist[SOLVE_HIST_TOTAL + 1];
+    const int nitems = nbig + ((total - nbig + 1) >> 1);
+    if ((int)blockIdx.x >= nitems) {
+        // the histogram has been consumed by the order kernel: the last block clears it for the next step
+        // (bins only: the other blocks of this launch still read the total)
+        if (blockIdx.x == gridDim.x - 1)
+            for (int k = lane; k < SOLVE_HIST_TOTAL; k += WAVE) S.solve_hist[k] = 0;
+        return;
+    }
+    solve_item<NPAD, PRIO>(P, S, io, (int)blockIdx.x, nbig, total, lane, L);
+}
+template <int NPAD>
+__global__ __launch_bounds__(WAVE) void env_step_solve_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
+    solve_block<NPAD, false>(P, S, io);
+}
+// The same with the issue priority of every solve following the work it has left (SolvePriority): for launches that
+// the chip holds in one round, where the solves of a SIMD should finish together.
+template <int NPAD>
+__global__ __launch_bounds__(WAVE) void env_step_solve_prio_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
+    solve_block<NPAD, true>(P, S, io);
 }
 
 // ------------------------------------------------------------------ reset kernel (N <= 64)
@@ -2921,6 +3027,24 @@ size_t workspace_bytes(int N, int E) {
         default: MARL_LAUNCH_NPAD(64, kern, grid, lds, stream, __VA_ARGS__); break;            \
     }
 
+// Priorities in the solve launch pay while the chip holds the launch in about one round of 16 waves per CU (about
+// 0.6 solve blocks per env: 8 192 envs on 256 CUs, 116 -> 111 us per step); with several rounds the blocks that end
+// early make room for the next ones, and holding them back costs (16 384 envs: 182 -> 188 us).
+enum { SOLVE_PRIORITY_ENVS_PER_CU = 40 };
+
+// Compute units of the current device (cached per device; 0 on error).
+int cu_count() {
+    static int cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int c = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+    if (c == 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1) return 0;
+        __atomic_store_n(&cached[dev], c, __ATOMIC_RELAXED);
+    }
+    return c;
+}
+
 }  // namespace
 
 // ====================================================================== C ABI
@@ -2979,7 +3103,7 @@ int marl_params_init(MarlEnvParams* p) {
     p->dt_f32 = (float)p->dt;
     p->v_max_f32 = (float)p->v_max;
     p->v_max_sq_f32 = (float)(p->v_max * p->v_max);
-    if (p->stage_flags & ~MARL_STAGE_NO_RECLUSTER) return MARL_EINVAL;
+    if (p->stage_flags & ~(MARL_STAGE_NO_RECLUSTER | MARL_STAGE_NO_SOLVE_PRIORITY)) return MARL_EINVAL;
     if (p->lambda2_rounds <= 0) p->lambda2_rounds = 8;
     return MARL_OK;
 }
@@ -3100,7 +3224,11 @@ int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepI
     hipLaunchKernelGGL(env_step_front_kernel<0>, dim3(s->E), dim3(WAVE), front_lds_bytes(), (hipStream_t)stream, *p, *s, *io);
     hipLaunchKernelGGL(solve_order_kernel, dim3((s->E + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, (int)s->E, *s);
     // one block more than envs: the last one never has a solve and clears the histogram
-    MARL_DISPATCH_NPAD(p->N, env_step_solve_kernel, dim3(s->E + 1), 0, stream, *p, *s, *io);
+    if (!(p->stage_flags & MARL_STAGE_NO_SOLVE_PRIORITY) && s->E <= SOLVE_PRIORITY_ENVS_PER_CU * cu_count()) {
+        MARL_DISPATCH_NPAD(p->N, env_step_solve_prio_kernel, dim3(s->E + 1), 0, stream, *p, *s, *io);
+    } else {
+        MARL_DISPATCH_NPAD(p->N, env_step_solve_kernel, dim3(s->E + 1), 0, stream, *p, *s, *io);
+    }
     return hip_check(hipGetLastError());
 }
 
@@ -3131,6 +3259,10 @@ int marl_env_step_parts(const MarlEnvParams* p, const MarlEnvState* s, const Mar
     int rc = part_bounds(p, s, parts, streams, scratch);
     if (rc != MARL_OK || io == nullptr) return rc != MARL_OK ? rc : MARL_EINVAL;
     const size_t n = p->N, m = p->M, w = (n + 31) / 32;
+    // Solves of several parts share the SIMDs with each other and with the other parts' front waves: a part's small
+    // solves had better leave early than wait for its large ones (measured: 104 against 107 us per step of 8 192 envs).
+    MarlEnvParams pp = *p;
+    if (parts > 1) pp.stage_flags |= MARL_STAGE_NO_SOLVE_PRIORITY;
     int32_t first = 0;
     for (int32_t k = 0; k < parts; ++k) {
         const int32_t count = s->E / parts + (k < s->E % parts ? 1 : 0);
@@ -3145,7 +3277,7 @@ int marl_env_step_parts(const MarlEnvParams* p, const MarlEnvState* s, const Mar
         o.reward_terms = rows_from(io->reward_terms, f, 5); o.avg_power_dbm = rows_from(io->avg_power_dbm, f, 1);
         o.adj_bits = rows_from(io->adj_bits, f, n * w); o.jam_bits = rows_from(io->jam_bits, f, n * w);
         o.env_offset = io->env_offset + f;
-        rc = marl_env_step(p, &part, &o, streams[k]);
+        rc = marl_env_step(&pp, &part, &o, streams[k]);
         if (rc != MARL_OK) return rc;
         first += count;
     }

@@ -61,6 +61,7 @@ class EnvConfig:
     omega_max: float = 0.5          # EnemySwarm default (enemy_swarm.py:60); JammerEnv does not expose it
     step_schedule: str = "auto"     # N <= 64: "auto", "fused" (one launch per step) or "split" (three, longest solve first)
     recluster: bool = True          # False: step() never re-clusters (the table of the last reset stays): "step + reward only"
+    solve_priority: bool = True     # split schedule: the issue priority of an eigen-solve follows the work it has left
 
     @staticmethod
     def fast_preset(N: int = 10, M: int = 4, **kw) -> "EnvConfig":
@@ -82,7 +83,7 @@ class EnvConfig:
         p.random_jammer_start = int(bool(self.random_jammer_start))
         p.max_reset_attempts = int(self.max_reset_attempts)
         p.lambda2_rounds = int(self.lambda2_rounds)
-        p.stage_flags = 0 if self.recluster else _lib.STAGE_NO_RECLUSTER
+        p.stage_flags = (0 if self.recluster else _lib.STAGE_NO_RECLUSTER) | (0 if self.solve_priority else _lib.STAGE_NO_SOLVE_PRIORITY)
         p.arena_size, p.dt, p.v_max, p.v_enemy = float(self.arena_size), float(self.dt), float(self.v_max), float(self.v_enemy)
         p.P_tx_w, p.P_sens_w = db_to_watts(self.P_tx_dbm), db_to_watts(self.P_sens_dbm)
         p.P_jam_w, p.P_thr_w = db_to_watts(self.P_jammer_dbm), db_to_watts(self.P_jam_thresh_dbm)
