@@ -38,8 +38,8 @@ def stats(out, dbp):
     print(open(out).read())
 
 
-STEP_KERNELS = ("env_step_front_kernel", "solve_order_kernel", "env_step_solve_kernel", "env_step_big_kernel",
-                "env_step_team_kernel")
+STEP_KERNELS = ("env_step_front_kernel", "solve_order_kernel", "env_step_solve_kernel", "env_step_solve_prio_kernel",
+                "env_step_big_kernel", "env_step_team_kernel")
 
 
 def pmc(out, dbs):
@@ -56,7 +56,7 @@ def pmc(out, dbs):
                 continue
             per[cname][k] += val
             disp[k].add(did)
-        steps = max((len(v) for k, v in disp.items() if k.startswith(("env_step_solve_kernel", "env_step_big_kernel"))),
+        steps = max((len(v) for k, v in disp.items() if k.startswith(("env_step_solve_kernel", "env_step_solve_prio_kernel", "env_step_big_kernel"))),
                     default=0)
         for cname, byk in per.items():
             res["per_step"][cname] = sum(byk.values()) / steps
@@ -76,7 +76,7 @@ def summary(out, stats_csv, pmc_json=None):
         if row["AverageNs"]:
             res["kernel_avg_us"][row["Name"]] = float(row["AverageNs"]) / 1e3
     for k, v in res["kernel_avg_us"].items():
-        if k.startswith(("env_step_solve_kernel", "env_step_team_kernel")):
+        if k.startswith(("env_step_solve_kernel", "env_step_solve_prio_kernel", "env_step_team_kernel")):
             res["solve_kernel_us"] = v
     if pmc_json:
         p = json.load(open(pmc_json))
