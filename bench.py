@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 CONFIGS = {
     2: dict(E=4096, N=10, M=4, steps=2000, warmup=100, reward_only=True,
             name="BASELINE configs[1]: step + reward only (no re-clustering in the step, no observation output)"),
-    3: dict(E=8192, N=50, M=8, steps=400, warmup=50, reward_only=False,
+    3: dict(E=8192, N=50, M=8, steps=2000, warmup=200, reward_only=False,
             name="BASELINE configs[2]: full JammerEnv step incl. DBSCAN + lambda2"),
     4: dict(E=8192, N=200, M=16, steps=20, warmup=3, reward_only=False,
             name="BASELINE configs[3]: large swarm, full step (lambda2 eigen-solve and N^2 FSPL dominate)"),
