@@ -222,7 +222,8 @@ __device__ __forceinline__ void enemy_spawn(const MarlEnvParams& P, const MarlEn
 // ------------------------------------------------------------------ LDS layout of one env
 struct WaveLds {
     double2 sxy[WAVE];                // enemy positions (x, y): one 16-byte read per enemy in the pair loops
-    float2 sxyf[WAVE];                // the same in float32: first-stage jamming tests of the step
+    float sxf[WAVE], syf[WAVE];       // the same in float32, x and y apart (pairs of neighbours are read as one packed operand);
+                                      // entries beyond the swarm hold 1e30: first-stage jamming tests of the step
     double jx[WAVE], jy[WAVE];        // jammer positions
     unsigned long long xfer[WAVE];    // lane-to-lane hand-over of 64-bit rows
     double cx[WAVE + 2], cy[WAVE + 2];  // centroids in dict order
@@ -313,27 +314,45 @@ __device__ __forceinline__ void pair_pass(const WaveLds& L, int n, int lane, dou
 // lie in [0, A]^2).  `sure` = within the lower threshold (the exact test holds), `maybe` = within the upper one;
 // a pair that is `maybe` for some jammer and `sure` for none is settled afterwards by the exact float64
 // expression, so float32 never decides a bit.
+typedef float v2f __attribute__((ext_vector_type(2)));
 template <int KJ>
 __device__ __forceinline__ void jam_pass_f32(const WaveLds& L, int n, int lane, float thr_lo, float thr_hi,
                                              const float (&q2x)[4], const float (&q2y)[4], uint64_t& sure, uint64_t& maybe) {
-    const float2 pi = L.sxyf[lane & (WAVE - 1)];
-    uint32_t s_lo = 0, s_hi = 0, m_lo = 0, m_hi = 0;
-    auto body = [&](int j, uint32_t bit, uint32_t& sb, uint32_t& mb) {
-        const float2 pj = L.sxyf[j];
-        const float sx = pi.x + pj.x, sy = pi.y + pj.y;
-        bool hs = false, hm = false;
-        static_for<0, KJ>([&](auto k) {
-            const float DX = q2x[decltype(k)::value] - sx, DY = q2y[decltype(k)::value] - sy;
-            const float d2 = fmaf(DX, DX, DY * DY);
-            hs |= (d2 <= thr_lo);
-            hm |= (d2 <= thr_hi);
-        });
-        sb |= hs ? bit : 0u;
-        mb |= hm ? bit : 0u;
+    // Two enemies j, j + 1 per iteration on the packed float32 pipe (v_pk_add / mul / fma: the same IEEE operations as
+    // one at a time).  Per pair of points the smallest squared distance over the jammers decides; its tests are the
+    // sign bits of d2 - t for t = the float after each threshold (d2 < t <=> d2 <= threshold), shifted into the
+    // row words by one v_alignbit each - in reverse order, turned round at the end.
+    const float xi = L.sxf[lane & (WAVE - 1)], yi = L.syf[lane & (WAVE - 1)];
+    const v2f xi2 = {xi, xi}, yi2 = {yi, yi};
+    const float tl = nextafterf(thr_lo, INFINITY), th = nextafterf(thr_hi, INFINITY);
+    const v2f tl2 = {tl, tl}, th2 = {th, th};
+    auto word = [&](int j0, int cnt, uint32_t& sb, uint32_t& mb) {      // cnt even, 2 .. 32
+        uint32_t sw = 0, mw = 0;
+        for (int j = j0; j < j0 + cnt; j += 2) {
+            const v2f xj = *reinterpret_cast<const v2f*>(&L.sxf[j]), yj = *reinterpret_cast<const v2f*>(&L.syf[j]);
+            const v2f sx = xi2 + xj, sy = yi2 + yj;
+            v2f dmin = {0.0f, 0.0f};
+            static_for<0, KJ>([&](auto k) {
+                const v2f qx = {q2x[decltype(k)::value], q2x[decltype(k)::value]};
+                const v2f qy = {q2y[decltype(k)::value], q2y[decltype(k)::value]};
+                const v2f DX = qx - sx, DY = qy - sy;
+                const v2f d2 = __builtin_elementwise_fma(DX, DX, DY * DY);
+                if constexpr (decltype(k)::value == 0) dmin = d2;
+                else dmin = v2f{fminf(dmin.x, d2.x), fminf(dmin.y, d2.y)};
+            });
+            const v2f a = dmin - tl2, b = dmin - th2;
+            sw = __builtin_amdgcn_alignbit(sw, __float_as_uint(a.x), 31);
+            sw = __builtin_amdgcn_alignbit(sw, __float_as_uint(a.y), 31);
+            mw = __builtin_amdgcn_alignbit(mw, __float_as_uint(b.x), 31);
+            mw = __builtin_amdgcn_alignbit(mw, __float_as_uint(b.y), 31);
+        }
+        sb |= __brev(sw) >> (32 - cnt);
+        mb |= __brev(mw) >> (32 - cnt);
     };
-    const int n_lo = n < 32 ? n : 32;
-    for (int j = 0; j < n_lo; ++j) body(j, 1u << j, s_lo, m_lo);
-    for (int j = 32; j < n; ++j) body(j, 1u << (j - 32), s_hi, m_hi);
+    uint32_t s_lo = 0, s_hi = 0, m_lo = 0, m_hi = 0;
+    const int n_lo = n < 32 ? ((n + 1) & ~1) : 32;
+    word(0, n_lo, s_lo, m_lo);
+    if (n > 32) word(32, (n - 32 + 1) & ~1, s_hi, m_hi);
     sure |= ((uint64_t)s_hi << 32) | s_lo;
     maybe |= ((uint64_t)m_hi << 32) | m_lo;
 }
@@ -1354,7 +1373,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 
         if (ct) S.enemy_omega[oi] = ew;
         S.enemy_x[oi] = ex; S.enemy_y[oi] = ey; S.enemy_vx[oi] = evx; S.enemy_vy[oi] = evy;
         L.sxy[lane] = make_double2(ex, ey);
-        L.sxyf[lane] = make_float2((float)ex, (float)ey);
+        L.sxf[lane] = (float)ex; L.syf[lane] = (float)ey;
+    } else {
+        L.sxf[lane] = 1e30f; L.syf[lane] = 1e30f;          // squares overflow to +inf: never within range
     }
     WSYNC();
     FSTAMP(0);
