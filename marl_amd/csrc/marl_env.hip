@@ -101,13 +101,15 @@ using namespace marl_rng;
 // Two independent N(0, sigma) draws for enemy `i` of env `genv` at step `step`.
 __device__ __forceinline__ void noise_pair(uint64_t seed, uint64_t genv, uint32_t step, uint32_t i,
                                            double sigma, double& nx, double& ny) {
-    uint32_t r[4];
-    philox4x32((uint32_t)genv, (uint32_t)(genv >> 32) ^ (i << 8) ^ STREAM_NOISE, step, i,
-               (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    // counter = (env, step's low 24 bits | drone), key = seed mixed with the stream id and the bits that do not fit
+    uint32_t r[2];
+    philox2x32((uint32_t)genv, (step << 8) | (i & 0xFFu),
+               (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u) ^ ((uint32_t)(genv >> 32) * 0x85EBCA6Bu) ^
+                   ((step >> 24) * 0xC2B2AE35u) ^ ((uint32_t)STREAM_NOISE << 28), r);
     // Box-Muller with the hardware's single-precision log2 / sin / cos (v_log_f32, v_sin_f32 and
     // v_cos_f32 take their argument in revolutions): these draws have no counterpart in the reference,
     // only their distribution matters, and seven good digits of it are plenty.
-    const float u1 = (float)u01(r[0], r[1]), u2 = (float)u01(r[2], r[3]);      // u1 >= 2^-54 > 0
+    const float u1 = u01f(r[0]), u2 = u01f(r[1]);                              // u1 >= 2^-25 > 0
     const double rad = (double)__builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * sigma;   // -2 ln 2 * log2
     const double s = (double)__builtin_amdgcn_sinf(u2), c = (double)__builtin_amdgcn_cosf(u2);
     nx = rad * c; ny = rad * s;

@@ -22,6 +22,21 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+// Philox2x32-10 (same paper): 64-bit counter, 32-bit key, two words out - half the multiplications of the 4x32
+// form (32-bit integer multiplies run at a quarter of the vector rate), for consumers that need 64 bits per draw.
+__device__ __forceinline__ void philox2x32(uint32_t c0, uint32_t c1, uint32_t k, uint32_t out[2]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p = (uint64_t)0xD256D193u * c0;
+        c0 = (uint32_t)(p >> 32) ^ k ^ c1;
+        c1 = (uint32_t)p;
+        k += 0x9E3779B9u;
+    }
+    out[0] = c0; out[1] = c1;
+}
+__device__ __forceinline__ float u01f(uint32_t r) {                  // (0,1), 24 bits, float32
+    return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
 __device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {   // (0,1), 53 bits
     const uint64_t v = ((uint64_t)hi << 21) ^ (uint64_t)(lo >> 11);
     return ((double)(v & ((1ull << 53) - 1)) + 0.5) * (1.0 / 9007199254740992.0);
