@@ -572,6 +572,11 @@ __device__ __forceinline__ double column_of(const double (&a)[NPAD], int i) {
 // full to the end.  Work left, in instructions: about 85 + 3 i per Householder step that reduces row i, then 4 per
 // term and round of the eigenvalue search; the four levels of the hardware are spaced more finely towards the end,
 // where the finishing order is decided.
+#ifndef SOLVE_PRIO_T3            /* level thresholds, per cent of the largest solve's work */
+#define SOLVE_PRIO_T3 30
+#define SOLVE_PRIO_T2 15
+#define SOLVE_PRIO_T1 6
+#endif
 template <bool ON>
 struct SolvePriority {
     int left, level, scale;       // scale: the work of the largest solve, the measure of the levels
@@ -597,14 +602,15 @@ struct SolvePriority {
             spend(0);
         }
     }
-    // Levels at 45 %, 24 % and 11 % of the top: closer together towards the end, where the finishing order is decided.
+    // Levels at 30 %, 15 % and 6 % of the top: closer together towards the end, where the finishing order is decided
+    // (45 / 24 / 11, 35 / 20 / 10 and 20 / 9 / 3 are within 1 % of it).
     // (Alternating between neighbouring levels from step to step, for a priority that follows the work continuously,
     // slowed every wave down by half: priority changes are not free.)
     __device__ __forceinline__ void spend(int cost) {
         if constexpr (!ON) return;
         left -= cost;
         const int x = left * 100;
-        const int lv = x >= 45 * scale ? 3 : x >= 24 * scale ? 2 : x >= 11 * scale ? 1 : 0;
+        const int lv = x >= SOLVE_PRIO_T3 * scale ? 3 : x >= SOLVE_PRIO_T2 * scale ? 2 : x >= SOLVE_PRIO_T1 * scale ? 1 : 0;
         if (lv != level && (lv < level || cost == 0)) {      // rises only at the start
             level = lv;
             set(lv);
