@@ -164,7 +164,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--shards", type=int, default=None,
-                    help="parts of the batch stepped on HIP streams of their own (default: 3 for config 3, else 1)")
+                    help="parts of the batch stepped on HIP streams of their own (default: 3 for config 3 and 2 for "
+                         "config 2 when at least 400 steps are timed, else 1)")
     ap.add_argument("--schedule", default=os.environ.get("MARL_BENCH_SCHEDULE", "auto"),
                     choices=["auto", "fused", "split"], help="EnvConfig.step_schedule (testing: A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -264,7 +265,10 @@ def main():
                  "fused_update": bool(tr.agent.fused_update)}
         env_for_stage = solo
     else:
-        shards = args.shards if args.shards is not None else {3: 3, 2: 2}.get(args.config, 1)
+        # Parts on streams of their own pay over long runs; a timed region of a few milliseconds that holds an auto-reset
+        # varies between 0.118 and 0.175 ms per step with three parts (tools/short_runs.sh: 20 steps, the same command
+        # four times), 0.110 +- 0.001 with one launch sequence: short runs take the one stream.
+        shards = args.shards if args.shards is not None else ({3: 3, 2: 2}.get(args.config, 1) if steps >= 400 else 1)
         env = BatchedJammerEnv(E, cfg, seed=1234, device=dev, auto_reset=True, env_offset=rank * E,
                                write_obs=not cfgd["reward_only"], num_shards=shards)
         env.reset()
