@@ -200,6 +200,17 @@ class BatchedJammerEnv:
                     first += count
                 self._part_streams = (C.c_void_p * S)(*[sh[3].cuda_stream for sh in self._shards])
                 self._part_scratch = C.c_void_p(sbase)
+                # The reset kernel is the only one here that uses private (scratch) memory, and a HIP queue sets that up
+                # at the first launch that needs it - some hundred microseconds per queue, which would otherwise fall
+                # into the first auto-reset of a rollout.  A masked reset that selects no env (every block returns at
+                # once, the state is not touched) pays it here.
+                none = torch.zeros(self.E, dtype=torch.uint8, device=self.device)
+                rio = MarlResetIO()
+                rio.mask, rio.obs = none.data_ptr(), self.obs.data_ptr()
+                _lib.check(self.lib.marl_env_reset_parts(C.byref(self.params), C.byref(self.state), C.byref(rio),
+                                                         S, self._part_streams, self._part_scratch), "marl_env_reset_parts")
+                for sh in self._shards:
+                    sh[3].synchronize()
         self._episode = 0
         # Host-side bounds on the envs' step counters (min, max); None = unknown.  While the largest
         # counter cannot have reached max_steps no env is truncated and the masked auto-reset launch is
