@@ -200,10 +200,10 @@ class BatchedJammerEnv:
                     first += count
                 self._part_streams = (C.c_void_p * S)(*[sh[3].cuda_stream for sh in self._shards])
                 self._part_scratch = C.c_void_p(sbase)
-                # The reset kernel is the only one here that uses private (scratch) memory, and a HIP queue sets that up
-                # at the first launch that needs it - some hundred microseconds per queue, which would otherwise fall
-                # into the first auto-reset of a rollout.  A masked reset that selects no env (every block returns at
-                # once, the state is not touched) pays it here.
+                # The reset kernel is the only one here that is built with a private (scratch) segment (68 bytes that its
+                # code never touches), and a HIP queue sets scratch up at the first launch that asks for it - some hundred
+                # microseconds per queue, which would otherwise fall into the first auto-reset of a rollout.  A masked
+                # reset that selects no env (every block returns at once, the state is not touched) pays it here.
                 none = torch.zeros(self.E, dtype=torch.uint8, device=self.device)
                 rio = MarlResetIO()
                 rio.mask, rio.obs = none.data_ptr(), self.obs.data_ptr()
