@@ -168,6 +168,8 @@ def main():
                          "config 2 when at least 400 steps are timed, else 1)")
     ap.add_argument("--schedule", default=os.environ.get("MARL_BENCH_SCHEDULE", "auto"),
                     choices=["auto", "fused", "split"], help="EnvConfig.step_schedule (testing: A/B runs)")
+    ap.add_argument("--no-solve-priority", action="store_true",
+                    help="testing: EnvConfig.solve_priority=False (the solve launch leaves the wave priority alone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
@@ -215,7 +217,7 @@ def main():
         torch.cuda.synchronize()
 
     cfg = EnvConfig.fast_preset(N=N_ENEMY, M=M_JAM, recluster=not cfgd["reward_only"],
-                                step_schedule=args.schedule)
+                                step_schedule=args.schedule, solve_priority=not args.no_solve_priority)
     extra = {}
     if args.config == 5:
         from marl_amd.trainer import BatchedTrainer

@@ -3056,10 +3056,13 @@ size_t workspace_bytes(int N, int E) {
         default: MARL_LAUNCH_NPAD(64, kern, grid, lds, stream, __VA_ARGS__); break;            \
     }
 
-// Priorities in the solve launch pay while the chip holds the launch in about one round of 16 waves per CU (about
-// 0.6 solve blocks per env: 8 192 envs on 256 CUs, 116 -> 111 us per step); with several rounds the blocks that end
-// early make room for the next ones, and holding them back costs (16 384 envs: 182 -> 188 us).
-enum { SOLVE_PRIORITY_ENVS_PER_CU = 40 };
+// Priorities in the solve launch pay when the launch is about one round of the chip's wave slots (16 per CU; about 0.6
+// solve blocks per env): every slot then starts a solve at once and nothing follows, so what counts is that the four
+// solves of a SIMD end together.  With fewer blocks the SIMDs are not contended, with more the blocks that end early make
+// room for the next ones and holding them back costs.  On 256 CUs, one launch sequence, us per step with / without:
+// 4 096 envs 76.9 / 74.6, 6 144 envs 88.6 / 88.0, 7 168 envs 100.5 / 103.7, 8 192 envs 106.2 / 111.3, 9 216 envs
+// 118.9 / 117.8, 10 240 envs 133.0 / 127.5 (tools/prio_sweep.sh).
+enum { SOLVE_PRIORITY_ENVS_PER_CU_MIN = 26, SOLVE_PRIORITY_ENVS_PER_CU_MAX = 34 };
 
 // Compute units of the current device (cached per device; 0 on error).
 int cu_count() {
@@ -3253,7 +3256,8 @@ int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepI
     hipLaunchKernelGGL(env_step_front_kernel<0>, dim3(s->E), dim3(WAVE), front_lds_bytes(), (hipStream_t)stream, *p, *s, *io);
     hipLaunchKernelGGL(solve_order_kernel, dim3((s->E + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, (int)s->E, *s);
     // one block more than envs: the last one never has a solve and clears the histogram
-    if (!(p->stage_flags & MARL_STAGE_NO_SOLVE_PRIORITY) && s->E <= SOLVE_PRIORITY_ENVS_PER_CU * cu_count()) {
+    const int cus = (p->stage_flags & MARL_STAGE_NO_SOLVE_PRIORITY) ? 0 : cu_count();
+    if (cus > 0 && s->E >= SOLVE_PRIORITY_ENVS_PER_CU_MIN * cus && s->E <= SOLVE_PRIORITY_ENVS_PER_CU_MAX * cus) {
         MARL_DISPATCH_NPAD(p->N, env_step_solve_prio_kernel, dim3(s->E + 1), 0, stream, *p, *s, *io);
     } else {
         MARL_DISPATCH_NPAD(p->N, env_step_solve_kernel, dim3(s->E + 1), 0, stream, *p, *s, *io);
