@@ -735,9 +735,9 @@ def test_state_buffer_need_not_be_zeroed_before_the_first_full_reset():
 
 def test_split_schedules_equal_fused_schedule_over_episodes():
     """The three-launch step (histogram, counting sort, longest-first solves, hand-over buffers) must give
-    bit for bit what the one-launch step gives: 4 097 envs, 130 steps across two auto-resets, with the
-    optional outputs."""
-    E, N, M = 4097, 50, 8
+    bit for bit what the one-launch step gives: 8 191 envs (on 256 CUs a batch for which the solve launch sets
+    wave priorities), 130 steps across two auto-resets, with the optional outputs."""
+    E, N, M = 8191, 50, 8
     # the split schedule twice: with the solves' issue priority following their remaining work (the default), and without
     envs = [BatchedJammerEnv(E, EnvConfig.fast_preset(N=N, M=M, max_steps=60, step_schedule=s, solve_priority=pr), seed=21,
                              track_avg_power=True, debug_bits=True)
