@@ -156,6 +156,29 @@ def lambda2_stage_time(env, reps=10):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
+def launch_ranks(n, share_device):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this script (fresh interpreters, one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, the command line passed on) and wait for them.
+    Rank 0 prints the JSON line.  This process never initialises the GPU (counting devices does not)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if not share_device and have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    return next((c for c in codes if c != 0), 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +207,8 @@ def main():
     warmup = args.warmup if args.warmup is not None else cfgd["warmup"]
     E = args.envs_per_gpu if args.envs_per_gpu is not None else cfgd["E"]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, args.share_device))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -318,8 +343,11 @@ def main():
         env_for_stage = env
     if dist is not None:
         t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_ms = [float(x.item()) / steps * 1e3 for x in every]
+        elapsed = max(per_rank_ms) * steps * 1e-3
+        extra["per_rank_ms_per_step"] = per_rank_ms
     lam_mean = float(env.lambda2.mean())
     steps_per_s = world * E * steps / elapsed
 

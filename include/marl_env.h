@@ -248,12 +248,14 @@ int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t *bits, double *l
  * of the eigenproblem otherwise).  marl_state_bytes already includes the same amount for the step. */
 size_t marl_lambda2_workspace_bytes(int32_t N, int32_t E);
 
-/* The same as marl_lambda2_from_bits without a workspace argument and without any allocation.  It has no
+/* marl_lambda2_from_bits for N <= MARL_MAX_N (larger graphs: MARL_EUNSUPPORTED) without a workspace argument and
+ * without any allocation.  It has no
  * counterpart in the reference: it exists for callers that cannot call hipMalloc (code under HIP graph
  * capture, tight serving loops, harnesses that forbid allocation).  The scratch the solver needs for
  * N > 64 is a static device array of MARL_STATIC_SCRATCH_BYTES inside the library (one copy per GPU, held
  * until the process ends); a request with marl_lambda2_workspace_bytes(N, E) beyond that returns
- * MARL_ETOOBIG (32 MiB holds e.g. 104 envs at N = 200, 64 at N = 256; any E at N <= 64, which needs none).
+ * MARL_ETOOBIG (32 MiB holds e.g. 104 envs at N = 200, 63 at N = 256 -- the pending list of the second launch
+ * takes room beside the matrices --; any E at N <= 64, which needs none).
  * The first call on a device looks the array's address up (make that call outside graph capture).  All
  * calls on one GPU share the array: calls that overlap in time on one GPU (different streams) race. */
 #define MARL_STATIC_SCRATCH_BYTES (32u << 20)
@@ -283,6 +285,30 @@ int marl_reward_per_agent(const MarlEnvParams *p, int32_t E, const double *lambd
                           const int32_t *jam_band, const float *vx, const float *vy, const double *cent_x,
                           const double *cent_y, const int32_t *n_clusters, const int32_t *ncent,
                           const int32_t *assign, float *rewards, void *stream);
+
+/* RewardCalculator.compute (environment/reward.py:106-176: the five terms and their clipped weighted sum) and
+ * ObservationBuilder.build_vectorized (environment/observation.py:264-332) as a stage of their own, on tables in the
+ * layout of MarlEnvState (cent_* [E][N+1] in dict order, assign [E][M], vx / vy = last_vx / last_vy); with enemy_x /
+ * enemy_y and avg_power_dbm given, also JammerEnv._compute_avg_jamming_power (environment/jammer_env.py:510-560).
+ * The step computes the same quantities with the same device functions; this entry point makes them testable
+ * against the reference's stage outputs.  Output pointers may be NULL. */
+typedef struct MarlRewardObsIO {
+    const double *lambda2, *lambda2_initial;     /* [E] */
+    const int32_t *enemy_band;                   /* [E] */
+    const double *enemy_x, *enemy_y;             /* [E][N], only read for avg_power_dbm */
+    const double *jam_x, *jam_y;                 /* [E][M] */
+    const int32_t *jam_band;                     /* [E][M] */
+    const float *vx, *vy;                        /* [E][M] raw action velocities (float32: jammer_env.py:377-380) */
+    const double *cent_x, *cent_y;               /* [E][N+1] */
+    const int32_t *cent_size;                    /* [E][N+1] */
+    const int32_t *n_clusters, *ncent;           /* [E] */
+    const int32_t *assign;                       /* [E][M] */
+    float *reward;                               /* [E]       out */
+    float *reward_terms;                         /* [E][5]    out: unweighted r1..r5 */
+    float *obs;                                  /* [E][M][5] out */
+    double *avg_power_dbm;                       /* [E]       out */
+} MarlRewardObsIO;
+int marl_reward_obs(const MarlEnvParams *p, int32_t E, const MarlRewardObsIO *io, void *stream);
 
 /* ---- policy inference for the rollout loop ---------------------------------- */
 

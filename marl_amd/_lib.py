@@ -93,6 +93,12 @@ class MarlPpoApply(C.Structure):
     ]
 
 
+class MarlRewardObsIO(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "lambda2", "lambda2_initial", "enemy_band", "enemy_x", "enemy_y", "jam_x", "jam_y", "jam_band", "vx", "vy",
+        "cent_x", "cent_y", "cent_size", "n_clusters", "ncent", "assign", "reward", "reward_terms", "obs", "avg_power_dbm")]
+
+
 class MarlResetIO(C.Structure):
     _fields_ = [
         ("mask", _pu8), ("enemy_pos", _pd), ("enemy_vel", _pd), ("enemy_omega", _pd), ("enemy_band", _pi), ("jam_init", _pd),
@@ -131,6 +137,7 @@ SYMBOLS = {
                            C.c_void_p]),
     "marl_reward_per_agent": (C.c_int, [C.POINTER(MarlEnvParams), C.c_int32, _pd, _pd, _pi, _pd, _pd, _pi, _pf, _pf,
                                         _pd, _pd, _pi, _pi, _pi, _pf, C.c_void_p]),
+    "marl_reward_obs": (C.c_int, [C.POINTER(MarlEnvParams), C.c_int32, C.POINTER(MarlRewardObsIO), C.c_void_p]),
     "marl_policy_weight_count": (C.c_size_t, [C.c_int32]),
     "marl_policy_act": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
                                   C.POINTER(MarlPolicyIO), C.c_void_p]),

@@ -435,12 +435,10 @@ class PPOAgent:
     (ppo_agent.py:301), two optimisers, grad-norm clip 0.5 each, KL early stop at 0.03.
     """
 
-    GRAPH_MAX_BATCH = 256
-
     def __init__(self, obs_dim=5, hidden_dim=128, M=4, v_max=5.0, num_bands=4, log_std_min=-1.0, log_std_max=0.5,
                  gamma=0.99, gae_lambda=0.95, clip_eps=0.2, lr_actor=3e-4, lr_critic=1e-3, c1=0.5, c2=0.01,
                  max_grad_norm=0.5, rollout_length=2048, batch_size=256, n_epochs=10, device="auto", num_envs=1,
-                 seed: Optional[int] = None, graph_update: bool = True, fused_update: Optional[bool] = None):
+                 seed: Optional[int] = None, fused_update: Optional[bool] = None):
         self.obs_dim, self.hidden_dim, self.M, self.v_max, self.num_bands = obs_dim, hidden_dim, M, v_max, num_bands
         self.gamma, self.gae_lambda, self.clip_eps, self.c1, self.c2 = gamma, gae_lambda, clip_eps, c1, c2
         self.c2_initial, self.max_grad_norm = c2, max_grad_norm
@@ -455,21 +453,17 @@ class PPOAgent:
         if _dist_on():                       # every rank starts from rank 0's weights
             for p in list(self.actor.parameters()) + list(self.critic.parameters()):
                 torch.distributed.broadcast(p.data, src=0)
-        # On the GPU one minibatch step (forward, backward, clipping, both Adam steps: about a hundred
-        # small launches for these 36 k parameters) is captured into a HIP graph and replayed, which
-        # needs capturable optimisers with their learning rates, and the entropy weight, in device memory.
-        # Replays of the captured step were checked against eager steps: exact for minibatches of 64 and 256
-        # rows, but from a few thousand rows on the replayed backward pass of the stock torch kernels returns
-        # other gradients than the eager one (and scalar statistics that are not the batch's).  The graph is
-        # therefore only used where the step is launch-bound anyway: the reference's minibatch size.
-        self._graph_update = bool(graph_update) and self.device.type == "cuda" and batch_size <= self.GRAPH_MAX_BATCH
+        # On the GPU the learning rates and the entropy weight live in device memory: marl_ppo_apply reads
+        # them there, so a schedule changes them without a host round trip per step.  No torch kernel of the
+        # minibatch step is ever captured into a HIP graph (a captured autograd step replayed other gradients
+        # than the eager one for minibatches of a few thousand rows and more on this software stack; the
+        # library step below is six launches and needs none).
         on_gpu = self.device.type == "cuda"
         mk_lr = (lambda v: torch.tensor(float(v), device=self.device)) if on_gpu else float
         # fused: one launch per optimiser step instead of a dozen (same arithmetic, same state dict)
         self.actor_optimizer = torch.optim.Adam(self.actor.parameters(), lr=mk_lr(lr_actor), capturable=on_gpu, fused=on_gpu)
         self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr=mk_lr(lr_critic), capturable=on_gpu, fused=on_gpu)
         self._c2_t = torch.tensor(float(c2), device=self.device)
-        self._step_graph, self._step_static, self._eager_steps = None, None, 0
         self._sync = FlatGradSync([self.actor, self.critic])
         self.buffer = None
         if self.device.type == "cuda":
@@ -486,8 +480,8 @@ class PPOAgent:
         self._packed, self._packed_stale, self._act_calls = None, True, 0
         self.seed = 0 if seed is None else int(seed)
         # Minibatch step through libmarl_env.so (marl_ppo_rows: forward, losses and backward of every row in one
-        # launch; the sums over rows as a few GEMMs).  None = wherever the captured graph is not used.
-        self.fused_update = self.policy_kernel and ((not self._graph_update) if fused_update is None else bool(fused_update))
+        # launch; the sums over rows in a second one).  None = wherever the library has kernels for the networks' shape.
+        self.fused_update = self.policy_kernel and (True if fused_update is None else bool(fused_update))
         self._fz = None
 
     # -- acting (ppo_agent.py:193-225) ----------------------------------------
@@ -765,31 +759,6 @@ class PPOAgent:
         self._apply_gradients()
         return out
 
-    def _graphed_step(self, batch):
-        """Replays the captured minibatch step on `batch` (tensors of exactly batch_size rows).  Two
-        graphs -- gradients, then clip + Adam -- so that the all-reduce between them stays an ordinary
-        call on the stream: the replayed step is the same with one rank or many."""
-        if self._step_graph is None:
-            self._step_static = [torch.empty_like(t) for t in batch]
-            for d, t in zip(self._step_static, batch):
-                d.copy_(t)
-            # the statistics leave the graph through a tensor of ordinary memory; each graph keeps a pool of
-            # its own (what the second one allocates must not land on anything the first one still owns)
-            self._step_out = torch.zeros(5, dtype=torch.float64, device=self.device)
-            torch.cuda.synchronize(self.device)
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                self._step_out.copy_(self._forward_backward(*self._step_static))
-            with torch.cuda.graph(g2):
-                self._apply_gradients()
-            self._step_graph = (g1, g2)
-        for d, t in zip(self._step_static, batch):
-            d.copy_(t)
-        self._step_graph[0].replay()
-        self._sync.sync()
-        self._step_graph[1].replay()
-        return self._step_out
-
     def optimise(self, obs, actions, old_log_probs, advantages, returns, generator=None,
                  permutations=None) -> Dict[str, float]:
         """The epoch / minibatch loop of ppo_agent.py:286-354 on flattened device tensors.  Works on
@@ -832,13 +801,7 @@ class PPOAgent:
                     steps += 1
                     continue
                 batch = (obs[idx], actions[idx], old_log_probs[idx], advantages[idx], returns[idx])
-                # the first steps run eagerly (they create the optimiser state), short tail batches too
-                if self._graph_update and self._eager_steps >= 2 and idx.numel() == self.batch_size \
-                        and (self._step_static is None or self._step_static[0].shape[0] == self.batch_size):
-                    out = self._graphed_step(batch)
-                else:
-                    out = self._minibatch_step(*batch)
-                    self._eager_steps += 1
+                out = self._minibatch_step(*batch)
                 acc += out
                 epoch_kl += out[4]
                 nb += 1
@@ -888,10 +851,26 @@ class PPOAgent:
         path.mkdir(parents=True, exist_ok=True)
         stats = {k: [float(x) for x in v] for k, v in self.training_stats.items()}
         torch.save({"actor_state_dict": self.actor.state_dict(), "critic_state_dict": self.critic.state_dict(),
-                    "actor_optimizer_state_dict": self.actor_optimizer.state_dict(),
-                    "critic_optimizer_state_dict": self.critic_optimizer.state_dict(),
+                    "actor_optimizer_state_dict": self._portable_optimizer_state(self.actor_optimizer),
+                    "critic_optimizer_state_dict": self._portable_optimizer_state(self.critic_optimizer),
                     "total_timesteps": self.total_timesteps, "total_updates": self.total_updates,
                     "training_stats": stats, "config": self._config()}, path / "ppo_agent.pt")
+
+    @staticmethod
+    def _portable_optimizer_state(opt):
+        """state_dict() with the param groups as the reference's plain torch.optim.Adam writes them (float learning
+        rate, capturable=False, fused=None): PPOAgent.load of the reference (ppo_agent.py:430-435) hands them to
+        load_state_dict of such an optimiser, on CPU parameters too, where capturable / fused groups do not step."""
+        sd = opt.state_dict()
+        groups = []
+        for g in sd["param_groups"]:
+            g = dict(g)
+            g["lr"] = float(g["lr"])
+            g["capturable"], g["fused"] = False, None
+            groups.append(g)
+        state = {k: {n: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for n, v in st.items()}
+                 for k, st in sd["state"].items()}
+        return {"state": state, "param_groups": groups}
 
     @staticmethod
     def _read_checkpoint(path, map_location):
@@ -917,6 +896,7 @@ class PPOAgent:
             lr = float(g["lr"])
             g["lr"] = torch.tensor(lr, device=self.device) if on_gpu else lr
             g["capturable"] = on_gpu
+            g["fused"] = True if on_gpu else None
         for st in opt.state.values():
             if "step" in st and isinstance(st["step"], torch.Tensor):
                 st["step"] = st["step"].to(self.device if on_gpu else "cpu", torch.float32)
@@ -933,9 +913,6 @@ class PPOAgent:
             self.set_entropy_coef(float(ck["config"]["c2"]))
         if self._fz is not None:                       # the loaded moments into the flat vectors marl_ppo_apply steps
             self._flatten_optimizer_state()
-        # a captured step reads the tensors it was captured with: capture again after a load
-        self._step_graph, self._step_static = None, None
-        self._eager_steps = 0
         self._packed_stale = True
 
     def export_actor(self, path):

@@ -1873,6 +1873,56 @@ __global__ __launch_bounds__(WAVE) void reward_per_agent_kernel(MarlEnvParams P,
     rewards[o] = (float)(P.omega[0] * r1 + P.omega[1] * rb + P.omega[2] * rp - P.omega[3] * (double)re - P.omega[4] * r5);
 }
 
+// RewardCalculator.compute + ObservationBuilder.build_vectorized (+ the average jamming power) on caller tables:
+// the device functions of the step, behind an entry point of their own.  LDS = WaveLds (N <= 64) or BigLds<S>.
+template <class LDS>
+__device__ __forceinline__ void reward_obs_stage(const MarlEnvParams& P, const MarlRewardObsIO& io, LDS& L, int e, int lane,
+                                                 int num, int ncent, int eband) {
+    const int n = P.N, m = P.M, KS = n + 1;
+    if (lane < m) {
+        const size_t o = (size_t)e * m + lane;
+        L.jx[lane] = io.jam_x[o]; L.jy[lane] = io.jam_y[o]; L.jb[lane] = io.jam_band[o];
+        L.asg[lane] = io.assign[o];
+    }
+    for (int s = lane; s < ncent; s += WAVE) {
+        L.cx[s] = io.cent_x[(size_t)e * KS + s];
+        L.cy[s] = io.cent_y[(size_t)e * KS + s];
+        L.csz[s] = io.cent_size[(size_t)e * KS + s];
+    }
+    WSYNC();
+    const size_t oj = (size_t)e * m + (lane < m ? lane : 0);
+    const RewardOut rw = reward_obs_wave(P, n, m, lane, L, eband, num, ncent, io.lambda2[e], io.lambda2_initial[e],
+                                         io.vx[oj], io.vy[oj]);
+    if (lane < m && io.obs) {
+        float* o = io.obs + ((size_t)e * m + lane) * MARL_OBS_DIM;
+        o[0] = rw.o0; o[1] = rw.o1; o[2] = rw.o2; o[3] = rw.o3; o[4] = rw.o4;
+    }
+    if (lane == 0) {
+        if (io.reward) io.reward[e] = (float)rw.total;
+        if (io.reward_terms) {
+            float* r = io.reward_terms + (size_t)e * 5;
+            r[0] = rw.r0; r[1] = rw.r1; r[2] = rw.r2; r[3] = rw.r3; r[4] = rw.r4;
+        }
+    }
+}
+
+__global__ __launch_bounds__(WAVE) void reward_obs_kernel(MarlEnvParams P, MarlRewardObsIO io) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    WaveLds& L = carve(smem);
+    const int e = blockIdx.x, lane = threadIdx.x, n = P.N;
+    int eband = io.enemy_band[e];
+    eband = eband < 0 ? 0 : (eband > 3 ? 3 : eband);
+    int ncent = io.ncent[e];
+    ncent = ncent < 0 ? 0 : (ncent > n + 1 ? n + 1 : ncent);
+    const bool power = io.avg_power_dbm && io.enemy_x && io.enemy_y;
+    if (power && lane < n) L.sxy[lane] = make_double2(io.enemy_x[(size_t)e * n + lane], io.enemy_y[(size_t)e * n + lane]);
+    reward_obs_stage(P, io, L, e, lane, io.n_clusters[e], ncent, eband);
+    if (power) {
+        const double avgp = avg_power_wave(P, n, P.M, lane, L, eband);
+        if (lane == 0) io.avg_power_dbm[e] = avgp;
+    }
+}
+
 __global__ void fill_noise_kernel(MarlEnvParams P, MarlEnvState S, uint64_t seed, uint64_t env_offset, double* noise) {
     const int e = blockIdx.x, i = threadIdx.x;
     if (i >= P.N) return;
@@ -2945,6 +2995,30 @@ __global__ __launch_bounds__(WAVE) void dbscan_big_kernel(MarlEnvParams P, const
     if (lane == 0) { n_clusters[e] = num; ncent_out[e] = ncent; }
 }
 
+template <int S>
+__global__ __launch_bounds__(WAVE) void reward_obs_big_kernel(MarlEnvParams P, MarlRewardObsIO io) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    BigLds<S>& L = *reinterpret_cast<BigLds<S>*>(smem);
+    const int e = blockIdx.x, lane = threadIdx.x, n = P.N;
+    int eband = io.enemy_band[e];
+    eband = eband < 0 ? 0 : (eband > 3 ? 3 : eband);
+    int ncent = io.ncent[e];
+    ncent = ncent < 0 ? 0 : (ncent > n + 1 ? n + 1 : ncent);
+    const bool power = io.avg_power_dbm && io.enemy_x && io.enemy_y;
+    if (power) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int i = s * WAVE + lane;
+            if (i < n) { L.sx[i] = io.enemy_x[(size_t)e * n + i]; L.sy[i] = io.enemy_y[(size_t)e * n + i]; }
+        }
+    }
+    reward_obs_stage(P, io, L, e, lane, io.n_clusters[e], ncent, eband);
+    if (power) {
+        const double avgp = avg_power_big<S>(P, n, P.M, lane, L, eband);
+        if (lane == 0) io.avg_power_dbm[e] = avgp;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 int hip_check(hipError_t err) {
     if (err == hipSuccess) return MARL_OK;
@@ -3463,6 +3537,21 @@ int marl_reward_per_agent(const MarlEnvParams* p, int32_t E, const double* lambd
     hipLaunchKernelGGL(reward_per_agent_kernel, dim3(E), dim3(WAVE), 0, (hipStream_t)stream, *p, lambda2,
                        lambda2_initial, enemy_band, jam_x, jam_y, jam_band, vx, vy, cent_x, cent_y, n_clusters, ncent,
                        assign, rewards);
+    return hip_check(hipGetLastError());
+}
+
+int marl_reward_obs(const MarlEnvParams* p, int32_t E, const MarlRewardObsIO* io, void* stream) {
+    int rc = check_sizes(p);
+    if (rc != MARL_OK) return rc;
+    if (E < 1 || io == nullptr || !io->lambda2 || !io->lambda2_initial || !io->enemy_band || !io->jam_x || !io->jam_y ||
+        !io->jam_band || !io->vx || !io->vy || !io->cent_x || !io->cent_y || !io->cent_size || !io->n_clusters ||
+        !io->ncent || !io->assign)
+        return MARL_EINVAL;
+    if (p->N > WAVE) {
+        MARL_DISPATCH_SLOTS(p->N, reward_obs_big_kernel, dim3(E), stream, *p, *io);
+        return hip_check(hipGetLastError());
+    }
+    hipLaunchKernelGGL(reward_obs_kernel, dim3(E), dim3(WAVE), wave_lds_bytes(p->N), (hipStream_t)stream, *p, *io);
     return hip_check(hipGetLastError());
 }
 

@@ -9,6 +9,35 @@
 
 namespace marl_net {
 
+// Host-side per-device caches.  A process may drive several GPUs: the CU count and the "large dynamic LDS"
+// function attribute belong to the device that is current at the call, not to the process.
+constexpr int kMaxDevices = 64;
+inline int current_device_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
+    return dev;
+}
+// compute units of the current device (`fallback` when the query fails)
+inline int device_cus(int fallback) {
+    static int cached[kMaxDevices];
+    const int dev = current_device_slot();
+    if (dev < 0) return fallback;
+    int c = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+    if (c == 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1) c = fallback;
+        __atomic_store_n(&cached[dev], c, __ATOMIC_RELAXED);
+    }
+    return c;
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel AND device: `done` is the kernel's own table
+inline hipError_t allow_dynamic_lds(const void* kernel, size_t bytes, bool (&done)[kMaxDevices]) {
+    const int dev = current_device_slot();
+    if (dev >= 0 && __atomic_load_n(&done[dev], __ATOMIC_RELAXED)) return hipSuccess;
+    const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (err == hipSuccess && dev >= 0) __atomic_store_n(&done[dev], true, __ATOMIC_RELAXED);
+    return err;
+}
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 template <int I, int E, class F>

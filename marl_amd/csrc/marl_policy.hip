@@ -209,8 +209,6 @@ __global__ __launch_bounds__(POLICY_THREADS) void policy_act_kernel(const float*
     }
 }
 
-int g_cu_count = 0;
-
 }  // namespace
 
 extern "C" __attribute__((visibility("hidden"))) void marl_note_hip_error(int err);     // marl_env.hip
@@ -232,17 +230,11 @@ int marl_policy_act(int32_t E, int32_t M, int32_t hidden, float v_max, float log
         return MARL_EINVAL;
     if ((long long)E * M > (1ll << 30)) return MARL_EUNSUPPORTED;
     if (hidden != 64 && hidden != 128) return MARL_EUNSUPPORTED;
-    if (g_cu_count == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-            cus = 256;
-        g_cu_count = cus;
-    }
     // one workgroup per CU; the critic gets its share of them (tiles x matrix instructions per tile)
     const long long ta = ((long long)E * M + 31) / 32, tc = io->values ? (E + 31) / 32 : 0;
     const double wa = (double)ta * (hidden / 32 * 3 + hidden / 32 * hidden / 2 + hidden / 2);
     const double wc = (double)tc * (hidden / 32 * 3 + hidden / 32 * hidden / 2);
-    int grid = g_cu_count;
+    int grid = marl_net::device_cus(256);
     if (ta + tc < (long long)grid * POLICY_WAVES) grid = (int)((ta + tc + POLICY_WAVES - 1) / POLICY_WAVES) + (tc ? 1 : 0);
     int critic_blocks = tc ? (int)(grid * wc / (wa + wc) + 0.5) : 0;
     if (tc && critic_blocks < 1) critic_blocks = 1;
@@ -252,13 +244,9 @@ int marl_policy_act(int32_t E, int32_t M, int32_t hidden, float v_max, float log
     hipError_t err = hipSuccess;
 #define MARL_LAUNCH_POLICY(HH)                                                                                     \
     do {                                                                                                            \
-        static bool attr_set = false;                                                                               \
+        static bool attr_set[marl_net::kMaxDevices];                                                                \
         const size_t lds_bytes = (size_t)Pack<HH>::lds_floats * sizeof(float);                                      \
-        if (!attr_set) {                                                                                            \
-            err = hipFuncSetAttribute((const void*)policy_act_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)lds_bytes);                                                              \
-            attr_set = err == hipSuccess;                                                                           \
-        }                                                                                                           \
+        err = marl_net::allow_dynamic_lds((const void*)policy_act_kernel<HH>, lds_bytes, attr_set);                 \
         if (err == hipSuccess)                                                                                      \
             hipLaunchKernelGGL(policy_act_kernel<HH>, dim3(grid), dim3(POLICY_THREADS), lds_bytes, (hipStream_t)stream, \
                                io->weights, io->obs, io->tick, io->actions, io->log_probs, io->values, (int)E, (int)M, \

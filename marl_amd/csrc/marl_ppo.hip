@@ -737,8 +737,6 @@ __global__ __launch_bounds__(256) void ppo_pack_kernel(int n, const int32_t* __r
     }
 }
 
-int g_ppo_cus = 0;
-
 }  // namespace
 
 extern "C" __attribute__((visibility("hidden"))) void marl_note_hip_error(int err);     // marl_env.hip
@@ -753,15 +751,8 @@ size_t marl_ppo_weight_count(int32_t hidden) {
     }
 }
 
-static int ppo_cus() {
-    if (g_ppo_cus == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 2)
-            cus = 256;
-        g_ppo_cus = cus;
-    }
-    return g_ppo_cus;
-}
+// CUs of the current device: the caller sizes `partial` and `actor_sums` with the device current that it launches on
+static int ppo_cus() { return marl_net::device_cus(256); }
 
 int32_t marl_ppo_sum_rows(void) { return ppo_cus() * (PPO_THREADS / WAVE); }
 
@@ -787,13 +778,9 @@ int marl_ppo_products(int32_t B, int32_t hidden, const MarlPpoIO* io, float* par
     hipError_t err = hipSuccess;
 #define MARL_LAUNCH_PRODUCTS(HH)                                                                                     \
     do {                                                                                                              \
-        static bool attr_set = false;                                                                                 \
+        static bool attr_set[marl_net::kMaxDevices];                                                                  \
         const size_t lds_bytes = (size_t)ProductLayout<HH>::lds_floats * sizeof(float);                               \
-        if (!attr_set) {                                                                                              \
-            err = hipFuncSetAttribute((const void*)ppo_products_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)lds_bytes);                                                                \
-            attr_set = err == hipSuccess;                                                                             \
-        }                                                                                                             \
+        err = marl_net::allow_dynamic_lds((const void*)ppo_products_kernel<HH>, lds_bytes, attr_set);                 \
         if (err == hipSuccess)                                                                                        \
             hipLaunchKernelGGL(ppo_products_kernel<HH>, dim3(grid), dim3(PRODUCT_THREADS), lds_bytes, (hipStream_t)stream, \
                                *io, tiles, partial);                                                                  \
@@ -857,13 +844,10 @@ int marl_ppo_rows(int32_t B, int32_t hidden, const MarlPpoIO* io, void* stream) 
     hipError_t err = hipMemsetAsync(io->actor_sums, 0, (size_t)marl_ppo_sum_rows() * 4 * hidden * sizeof(float), (hipStream_t)stream);
 #define MARL_LAUNCH_PPO(HH, ACTOR, FLOATS)                                                                           \
     do {                                                                                                              \
-        static bool attr_set = false;                                                                                 \
+        static bool attr_set[marl_net::kMaxDevices];                                                                  \
         const size_t lds_bytes = (size_t)(FLOATS) * sizeof(float);                                                    \
-        if (err == hipSuccess && !attr_set) {                                                                         \
-            err = hipFuncSetAttribute((const void*)ppo_rows_kernel<HH, ACTOR>,                                        \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                    \
-            attr_set = err == hipSuccess;                                                                             \
-        }                                                                                                             \
+        if (err == hipSuccess)                                                                                        \
+            err = marl_net::allow_dynamic_lds((const void*)ppo_rows_kernel<HH, ACTOR>, lds_bytes, attr_set);          \
         const int waves = ROWS_THREADS<HH, ACTOR> / WAVE;                                                             \
         const int grid = tiles < cus * waves ? (tiles + waves - 1) / waves : cus;                                     \
         if (err == hipSuccess)                                                                                        \

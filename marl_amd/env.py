@@ -393,6 +393,32 @@ class BatchedJammerEnv:
                 _stream()), "marl_reward_per_agent")
         return out
 
+    def compute_lambda2(self, disrupted: bool = True) -> torch.Tensor:
+        """JammerEnv._compute_lambda2 (jammer_env.py:464-508) for the current state of every env, through the
+        stage ops: FSPL adjacency, minus the disrupted links when `disrupted`, Laplacian lambda2.  [E] float64."""
+        v = self.views
+        W = (self.N + 31) // 32
+        with torch.cuda.device(self.device):
+            adj = torch.zeros(self.E, self.N, W, dtype=torch.int32, device=self.device)
+            _lib.check(self.lib.marl_adjacency_bits(C.byref(self.params), self.E, v["enemy_x"].data_ptr(),
+                                                    v["enemy_y"].data_ptr(), v["enemy_band"].data_ptr(),
+                                                    adj.data_ptr(), _stream()), "marl_adjacency_bits")
+            if disrupted:
+                jam = torch.zeros_like(adj)
+                _lib.check(self.lib.marl_jam_mask_bits(C.byref(self.params), self.E, v["enemy_x"].data_ptr(),
+                                                       v["enemy_y"].data_ptr(), v["enemy_band"].data_ptr(),
+                                                       v["jam_x"].data_ptr(), v["jam_y"].data_ptr(),
+                                                       v["jam_band"].data_ptr(), jam.data_ptr(), _stream()),
+                           "marl_jam_mask_bits")
+                adj = (adj & ~jam).contiguous()
+            out = torch.zeros(self.E, dtype=torch.float64, device=self.device)
+            nb = self.lib.marl_lambda2_workspace_bytes(self.N, self.E)
+            ws = torch.empty(nb, dtype=torch.uint8, device=self.device) if nb else None
+            _lib.check(self.lib.marl_lambda2_from_bits(self.N, self.E, adj.data_ptr(), out.data_ptr(),
+                                                       self.params.lambda2_rounds, _ptr(ws), _stream()),
+                       "marl_lambda2_from_bits")
+        return out
+
     def fill_noise(self) -> torch.Tensor:
         """The enemy noise the next step() draws when called with noise=None."""
         out = torch.empty(self.E, self.N, 2, dtype=torch.float64, device=self.device)
@@ -649,6 +675,10 @@ class JammerEnv:
                 "enemy_positions": self.enemy_swarm.positions,
                 "avg_jamming_power_dbm": float(info_t["avg_jamming_power_dbm"][0].item())}
         return obs_t[0].cpu().numpy(), reward, False, bool(trunc_t[0].item()), info
+
+    def _compute_lambda2(self, disrupted: bool = True) -> float:
+        """jammer_env.py:464-508: lambda2 of the current swarm graph, with or without the jammed links."""
+        return float(self._b.compute_lambda2(disrupted)[0].item())
 
     def get_global_observation(self) -> np.ndarray:
         """Mean-pooled observation for the critic (observation.py:335-350)."""

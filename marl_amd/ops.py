@@ -10,6 +10,7 @@ The stage ops mirror the reference's pure functions:
     dbscan_labels       clustering/dbscan_clustering.py:78-144  DBSCANClusterer.fit
     gae                 agents/rollout_buffer.py:151-204        compute_returns_and_advantages
     reward_per_agent    environment/reward.py:308-396           RewardCalculator.compute_per_agent
+    reward_obs          environment/reward.py:106-176, observation.py:264-332   compute + build_vectorized
     env_step            environment/jammer_env.py:356-457       JammerEnv.step (state mutated in place)
 
 Bit matrices are int32 tensors [E, N, ceil(N/32)]: row i, bit j of word j // 32.
@@ -164,6 +165,38 @@ def reward_per_agent(state: torch.Tensor, handle: int, lambda2: torch.Tensor) ->
 def _(state, handle, lambda2):
     env = _ENVS[handle]
     return lambda2.new_empty((env.E, env.M), dtype=torch.float32)
+
+
+@torch.library.custom_op("marl_amd::reward_obs", mutates_args=())
+def reward_obs(state: torch.Tensor, handle: int, lambda2: torch.Tensor) -> List[torch.Tensor]:
+    """Reward stage + observation stage of the registered env's current state for the given lambda2 [E] f64:
+    [reward [E] f32, reward_terms [E,5] f32, obs [E,M,5] f32, avg_jamming_power_dbm [E] f64]."""
+    env = _ENVS[handle]
+    if state.data_ptr() != env._buf.data_ptr():
+        raise ValueError("state must be the buffer of the registered env")
+    _check_dev(lambda2)
+    v, dev = env.views, env.device
+    io = _lib.MarlRewardObsIO()
+    rew = torch.empty(env.E, dtype=torch.float32, device=dev)
+    terms = torch.empty(env.E, 5, dtype=torch.float32, device=dev)
+    obs = torch.empty(env.E, env.M, 5, dtype=torch.float32, device=dev)
+    avgp = torch.empty(env.E, dtype=torch.float64, device=dev)
+    io.lambda2, io.lambda2_initial = lambda2.data_ptr(), v["lambda2_initial"].data_ptr()
+    for name in ("enemy_band", "enemy_x", "enemy_y", "jam_x", "jam_y", "jam_band", "cent_x", "cent_y", "cent_size",
+                 "n_clusters", "ncent", "assign"):
+        setattr(io, name, v[name].data_ptr())
+    io.vx, io.vy = v["last_vx"].data_ptr(), v["last_vy"].data_ptr()
+    io.reward, io.reward_terms, io.obs, io.avg_power_dbm = rew.data_ptr(), terms.data_ptr(), obs.data_ptr(), avgp.data_ptr()
+    _lib.check(_lib.load().marl_reward_obs(C.byref(env.params), env.E, C.byref(io), _stream()), "marl_reward_obs")
+    return [rew, terms, obs, avgp]
+
+
+@reward_obs.register_fake
+def _(state, handle, lambda2):
+    env = _ENVS[handle]
+    f32 = torch.float32
+    return [lambda2.new_empty((env.E,), dtype=f32), lambda2.new_empty((env.E, 5), dtype=f32),
+            lambda2.new_empty((env.E, env.M, 5), dtype=f32), lambda2.new_empty((env.E,), dtype=torch.float64)]
 
 
 # -- the step itself: state lives in a BatchedJammerEnv, addressed by a small integer handle -------

@@ -700,9 +700,10 @@ def env_reset_with_retries(p: EnvParams, st: EnvState, attempts, jammer_init, ja
     return obs, info, used
 
 
-def env_step(p: EnvParams, st: EnvState, action, noise, want_avg_power: bool = True):
+def env_step(p: EnvParams, st: EnvState, action, noise, want_avg_power: bool = True, recluster: bool = True):
     """JammerEnv.step (jammer_env.py:356-457) with the (N,2) enemy noise draw
-    passed in.  `action` is the (M,3) array form (:376-378)."""
+    passed in.  `action` is the (M,3) array form (:376-378).  `recluster=False` leaves the
+    K_recompute block (jammer_env.py:394-402) out: the cluster table of the last reset stays."""
     st.step_count += 1
     action = np.asarray(action)
     velocity = action[:, :2]
@@ -718,7 +719,7 @@ def env_step(p: EnvParams, st: EnvState, action, noise, want_avg_power: bool = T
         st.enemy_pos, st.enemy_vel = enemy_step_random_walk(
             st.enemy_pos, st.enemy_vel, noise, p.v_enemy, p.dt, p.arena_size)
     reassigned = False
-    if st.step_count % p.K_recompute == 0:
+    if recluster and st.step_count % p.K_recompute == 0:
         cluster_fit(st.clusters, st.enemy_pos, p.eps, p.min_samples, p.arena_size)
         if should_reassign(st.clusters, p.drift_threshold):
             st.assign = assign_proportional(p.M, st.clusters)

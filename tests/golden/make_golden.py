@@ -221,6 +221,30 @@ def make_stage():
 
 
 # --------------------------------------------------------------------------
+# 1b. lambda2 through the reference's sparse branch (communication_graph.py:268-278), N > 256
+# --------------------------------------------------------------------------
+def make_lambda2_sparse():
+    """compute_lambda2(L, use_sparse=True) (scipy eigsh, which='SM') on graphs of 300, 640 and 1024 vertices:
+    connected sparse, dense and disconnected random graphs per size; the dense branch's value beside it."""
+    out = {}
+    k = 0
+    for n in (300, 640, 1024):
+        rng = np.random.RandomState(7000 + n)
+        for dens in (2.5 * np.log(n) / n, 0.3, 0.5 * np.log(n) / n):
+            upper = np.triu(rng.rand(n, n) < dens, 1)
+            A = (upper | upper.T).astype(np.float64)
+            L = cg.compute_laplacian(A)
+            out[f"g{k}_n"] = np.int32(n)
+            out[f"g{k}_adj"] = pack_rows(A)
+            out[f"g{k}_lam_sparse"] = np.float64(cg.compute_lambda2(L, use_sparse=True))
+            out[f"g{k}_lam_dense"] = np.float64(cg.compute_lambda2(L))
+            k += 1
+    out["n_graphs"] = np.int32(k)
+    np.savez_compressed(os.path.join(OUT, "lambda2_sparse.npz"), **out)
+    print("sparse-branch lambda2 graphs:", k)
+
+
+# --------------------------------------------------------------------------
 # 2. trajectories of the real JammerEnv
 # --------------------------------------------------------------------------
 def record_reset(env, seed, gstate):
@@ -678,7 +702,10 @@ if __name__ == "__main__":
         make_ct_trajectories()
     elif "--per-agent-only" in sys.argv:
         make_per_agent()
+    elif "--sparse-only" in sys.argv:
+        make_lambda2_sparse()
     else:
+        make_lambda2_sparse()
         make_per_agent()
         make_stage()
         make_edges()

@@ -220,3 +220,25 @@ def test_reference_checkpoint_loads_and_deploy_export_matches_minimal_actor(tmp_
     agent.save(tmp_path / "own")
     again = PPOAgent.from_checkpoint(tmp_path / "own", device="cpu")
     assert again.training_stats == agent.training_stats
+
+
+def test_saved_optimizer_state_loads_into_a_plain_adam_as_the_reference_does(tmp_path):
+    """PPOAgent.load of the reference (ppo_agent.py:430-435) hands the saved optimiser state to load_state_dict
+    of a plain torch.optim.Adam and goes on stepping: the file must hold float learning rates and
+    capturable=False / fused=None groups, whatever device wrote it."""
+    agent = PPOAgent(device="cpu", M=4, batch_size=64, n_epochs=1, seed=2)
+    agent.optimise(*_fake_rollout(256, 1))
+    agent.save(tmp_path / "ck")
+    ck = torch.load(tmp_path / "ck" / "ppo_agent.pt", map_location="cpu", weights_only=True)
+    for key, net in (("actor_optimizer_state_dict", Actor()), ("critic_optimizer_state_dict", Critic())):
+        g = ck[key]["param_groups"][0]
+        assert isinstance(g["lr"], float) and g["capturable"] is False and g["fused"] is None
+        net.load_state_dict(ck[key.replace("_optimizer", "")])
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        opt.load_state_dict(ck[key])
+        before = [p.detach().clone() for p in net.parameters()]
+        for p in net.parameters():
+            p.grad = torch.ones_like(p)
+        opt.step()
+        assert any(not torch.equal(a, b) for a, b in zip(before, net.parameters()))
+        assert float(next(iter(opt.state.values()))["step"]) == float(agent.actor_optimizer.state[next(iter(agent.actor.parameters()))]["step"]) + 1

@@ -95,30 +95,30 @@ def test_policy_kernel_draw_statistics():
     assert abs(float((zz[:, 0] * zz[:, 1]).mean())) < 0.05 and abs(float((zz[:-1, 0] * zz[1:, 0]).mean())) < 0.05
 
 
-def test_update_graph_is_limited_to_minibatches_where_replay_equals_eager():
-    """The captured minibatch step is used up to PPOAgent.GRAPH_MAX_BATCH rows; at that size every replay
-    gives the weights of the eager step."""
-    B = PPOAgent.GRAPH_MAX_BATCH
-    a = PPOAgent(device="cuda", M=4, batch_size=B, n_epochs=1, seed=1, graph_update=False, fused_update=False)
-    b = PPOAgent(device="cuda", M=4, batch_size=B, n_epochs=1, seed=1, graph_update=True)
-    big = PPOAgent(device="cuda", M=4, batch_size=4 * B, seed=1, graph_update=True)
-    assert b._graph_update and not a._graph_update and not big._graph_update
-    n = 10 * B
-    g = torch.Generator(device="cuda").manual_seed(2)
-    obs = torch.rand(n, 5, device="cuda", generator=g)
-    act = torch.cat([torch.randn(n, 2, device="cuda", generator=g), torch.randint(0, 4, (n, 1), device="cuda", generator=g).float()], 1)
-    adv, ret = torch.randn(n, device="cuda", generator=g), torch.randn(n, device="cuda", generator=g)
-    with torch.no_grad():
-        old = a.actor.evaluate_actions(obs, act)[0]
-    perm = [torch.randperm(n, generator=torch.Generator().manual_seed(3)).numpy()]
-    sa = a.optimise(obs, act, old, adv, ret, permutations=perm)
-    sb = b.optimise(obs, act, old, adv, ret, permutations=perm)
-    assert b._step_graph is not None
-    for p, q in zip(list(a.actor.parameters()) + list(a.critic.parameters()),
-                    list(b.actor.parameters()) + list(b.critic.parameters())):
-        assert torch.allclose(p, q, rtol=1e-6, atol=1e-8)
-    for k in sa:
-        assert abs(sa[k] - sb[k]) <= 1e-6 * max(1.0, abs(sa[k])), k
+def test_library_minibatch_step_equals_torch_step_at_small_and_large_minibatches():
+    """Every GPU agent takes the minibatch step through the library (marl_ppo_rows / products / apply), whatever
+    the minibatch size; one epoch of it gives the weights and statistics of the torch autograd step, at the
+    reference's 256 rows and at 8 192 rows."""
+    for B, n in ((256, 2560), (8192, 32768)):
+        a = PPOAgent(device="cuda", M=4, batch_size=B, n_epochs=1, seed=1, fused_update=False)
+        b = PPOAgent(device="cuda", M=4, batch_size=B, n_epochs=1, seed=1)
+        assert b.fused_update and not a.fused_update
+        g = torch.Generator(device="cuda").manual_seed(2)
+        obs = torch.rand(n, 5, device="cuda", generator=g)
+        act = torch.cat([torch.randn(n, 2, device="cuda", generator=g),
+                         torch.randint(0, 4, (n, 1), device="cuda", generator=g).float()], 1)
+        adv, ret = torch.randn(n, device="cuda", generator=g), torch.randn(n, device="cuda", generator=g)
+        with torch.no_grad():
+            old = a.actor.evaluate_actions(obs, act)[0]
+        perm = [torch.randperm(n, generator=torch.Generator().manual_seed(3)).numpy()]
+        sa = a.optimise(obs, act, old, adv, ret, permutations=perm)
+        sb = b.optimise(obs, act, old, adv, ret, permutations=perm)
+        for p, q in zip(list(a.actor.parameters()) + list(a.critic.parameters()),
+                        list(b.actor.parameters()) + list(b.critic.parameters())):
+            moved = 10 * 3e-3          # at most lr-sized moves per step
+            assert float((p.detach() - q.detach()).abs().max()) <= 2e-2 * moved
+        for k in sa:
+            assert abs(sa[k] - sb[k]) <= 2e-4 * max(1.0, abs(sa[k])), k
 
 
 def test_episode_statistics_from_the_step_kernels():

@@ -31,7 +31,7 @@ def make_rows(agent, n, seed, scale_heads=4.0):
 
 @pytest.mark.parametrize("hidden,B,n", [(128, 4096, 9000), (64, 1000, 1000), (128, 37, 64), (128, 65536, 70000)])
 def test_fused_gradients_equal_autograd(hidden, B, n):
-    agent = PPOAgent(device="cuda", hidden_dim=hidden, M=4, batch_size=B, seed=3, graph_update=False, fused_update=True)
+    agent = PPOAgent(device="cuda", hidden_dim=hidden, M=4, batch_size=B, seed=3, fused_update=True)
     assert agent.fused_update
     obs, act, old, adv, ret = make_rows(agent, n, 11)
     idx = torch.randperm(n, device="cuda")[:B].contiguous()
@@ -64,7 +64,7 @@ def test_train_packer_is_the_packing():
 def test_apply_is_clip_and_adam():
     """marl_ppo_apply against clip_grad_norm_ + torch.optim.Adam (ppo_agent.py:324-331) on the same gradients: norms
     above and below the clip threshold, three steps, then the packed weights it leaves for the next row pass."""
-    agents = [PPOAgent(device="cuda", M=4, seed=4, graph_update=False, fused_update=f) for f in (False, True)]
+    agents = [PPOAgent(device="cuda", M=4, seed=4, fused_update=f) for f in (False, True)]
     eager, fused = agents
     fused.actor.load_state_dict(eager.actor.state_dict())
     fused.critic.load_state_dict(eager.critic.state_dict())
@@ -94,7 +94,7 @@ def test_fused_agent_resumes_an_eager_checkpoint(tmp_path):
     """A checkpoint written after eager updates, loaded into an agent that steps through marl_ppo_apply: the next
     update starts from the saved moments and step counts (ppo_agent.py:386-458)."""
     n, B = 4096, 1024
-    eager = PPOAgent(device="cuda", M=4, batch_size=B, n_epochs=1, seed=12, graph_update=False, fused_update=False)
+    eager = PPOAgent(device="cuda", M=4, batch_size=B, n_epochs=1, seed=12, fused_update=False)
     g = torch.Generator(device="cuda").manual_seed(6)
     obs = torch.randn(n, 5, device="cuda", generator=g)
     act = torch.randn(n, 3, device="cuda", generator=g) * 3
@@ -106,7 +106,7 @@ def test_fused_agent_resumes_an_eager_checkpoint(tmp_path):
     perms = [np.random.RandomState(3).permutation(n)]
     eager.optimise(obs, act, old, adv, ret, permutations=perms)
     eager.save(tmp_path)
-    fused = PPOAgent(device="cuda", M=4, batch_size=B, n_epochs=1, seed=13, graph_update=False, fused_update=True)
+    fused = PPOAgent(device="cuda", M=4, batch_size=B, n_epochs=1, seed=13, fused_update=True)
     fused.optimise(obs, act, old, adv, ret, permutations=perms)          # its flat state exists before the load
     fused.load(tmp_path)
     before = {k: v.clone() for k, v in eager.actor.state_dict().items()}
@@ -128,7 +128,7 @@ def test_fused_update_follows_eager_update(n):
     """Whole optimise() calls: fused against eager torch on the same rows and permutations (n = 8500: a short last
     minibatch per epoch)."""
     B = 1024
-    agents = [PPOAgent(device="cuda", M=4, batch_size=B, n_epochs=2, seed=9, graph_update=False, fused_update=f)
+    agents = [PPOAgent(device="cuda", M=4, batch_size=B, n_epochs=2, seed=9, fused_update=f)
               for f in (False, True)]
     agents[1].actor.load_state_dict(agents[0].actor.state_dict())
     agents[1].critic.load_state_dict(agents[0].critic.state_dict())

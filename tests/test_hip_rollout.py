@@ -87,6 +87,25 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert d["value"] > 0 and abs(d["value"] - 2 * 512 * 20 / (d["ms_per_step"] * 20e-3)) / d["value"] < 1e-6
 
 
+@pytest.mark.gpu
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks of its own (here both on the one
+    visible GPU, over gloo) and rank 0 prints one line for the two of them."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--envs-per-gpu", "512", "--backend", "gloo", "--share-device"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and "cpu_baseline" not in d
+    assert len(d["per_rank_ms_per_step"]) == 2 and max(d["per_rank_ms_per_step"]) == pytest.approx(d["ms_per_step"])
+    assert abs(d["value"] - 2 * 512 * 20 / (d["ms_per_step"] * 20e-3)) / d["value"] < 1e-6
+
+
 def test_auto_reset_launch_is_skipped_only_when_nothing_can_be_done():
     """The masked auto-reset launch is left out while no step counter can have reached max_steps (host-side
     bounds).  An env that keeps the bounds and one that always launches must stay identical, also after
@@ -153,19 +172,20 @@ def _load_state(z, prefix, module):
     module.load_state_dict({k: torch.from_numpy(z[f"{prefix}_{k}"].copy()) for k in module.state_dict().keys()})
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_update_reproduces_reference_update_on_device(graph):
+@pytest.mark.parametrize("fused", [False, True])
+def test_update_reproduces_reference_update_on_device(fused):
     """PPOAgent.update of the reference (agents/ppo_agent.py:250-373) recorded with its weights before and
     after: the device agent (E = 1) is given the same weights, the same 64 transitions through
     DeviceRolloutBuffer.add, the same shuffles; GAE runs in marl_gae, the eight optimiser steps on the GPU
-    (eagerly, and with the two-graph replay after the first two).  Statistics to 1e-4.  Weights: Adam divides
+    (torch autograd + torch.optim, and the library's marl_ppo_* step).  Statistics to 1e-4.  Weights: Adam divides
     the gradient by its running magnitude, so in these first steps an element whose gradient is near zero
     moves by up to the learning rate in a direction that float32 summation order decides; the bar is
     therefore on the update itself -- every element within 1 % of the tensor's largest change, and the
     mean deviation below 0.1 % of it."""
     z, T, M, B, epochs = _ppo_golden()
     agent = PPOAgent(device="cuda", M=M, rollout_length=T, batch_size=B, n_epochs=epochs, num_envs=1,
-                     graph_update=graph)
+                     fused_update=fused)
+    assert agent.fused_update == fused
     _load_state(z, "a0", agent.actor)
     _load_state(z, "c0", agent.critic)
     for t in range(T):
@@ -173,8 +193,6 @@ def test_update_reproduces_reference_update_on_device(graph):
                                z["buf_rewards"][t:t + 1], z["buf_dones"][t:t + 1] > 0, z["buf_values"][t:t + 1])
     stats = agent.update(torch.from_numpy(z["last_obs"]).cuda()[None], torch.zeros(1, dtype=torch.bool, device="cuda"),
                          permutations=z["perms"])
-    if graph:
-        assert agent._step_graph is not None            # steps 3..8 were replays
     for prefix, net in (("a1", agent.actor), ("c1", agent.critic)):
         for k, v in net.state_dict().items():
             want = torch.from_numpy(z[f"{prefix}_{k}"]).cuda()
@@ -203,7 +221,7 @@ def test_gpu_checkpoint_resume_and_reference_checkpoint_then_update(tmp_path):
         return agent.optimise(obs, act, old, adv, ret, generator=g)
 
     a = PPOAgent(device="cuda", M=4, batch_size=256, n_epochs=1, seed=3)
-    run(a, 1)                                             # 8 steps: 2 eager, capture, 5 replays
+    run(a, 1)
     a.save(tmp_path / "ck")
     b = PPOAgent.from_checkpoint(tmp_path / "ck", device="cuda")
     assert isinstance(b.actor_optimizer.param_groups[0]["lr"], torch.Tensor)
@@ -213,7 +231,7 @@ def test_gpu_checkpoint_resume_and_reference_checkpoint_then_update(tmp_path):
         assert abs(sa[k] - sb[k]) <= 1e-5 * max(1.0, abs(sa[k])), k
     for p, q in zip(a.actor.parameters(), b.actor.parameters()):
         assert torch.allclose(p, q, rtol=1e-5, atol=1e-7)
-    b.set_learning_rate(1e-5, 2e-5)                       # reaches the replayed step
+    b.set_learning_rate(1e-5, 2e-5)                       # in place: the library step reads the device scalar
     assert abs(float(b.actor_optimizer.param_groups[0]["lr"]) - 1e-5) < 1e-12
     run(b, 3)
     # GPU checkpoint on the CPU
@@ -227,7 +245,7 @@ def test_gpu_checkpoint_resume_and_reference_checkpoint_then_update(tmp_path):
     assert st["step"].is_cuda and float(st["step"]) == 8.0
     r.batch_size = 256
     out = run(r, 4)
-    assert r._step_graph is not None and all(np.isfinite(v) for v in out.values())
+    assert all(np.isfinite(v) for v in out.values())
 
 
 # ---------------------------------------------------------------- BASELINE configs[4]: rollouts at N=50, M=8
