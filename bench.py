@@ -193,6 +193,8 @@ def main():
                     choices=["auto", "fused", "split"], help="EnvConfig.step_schedule (testing: A/B runs)")
     ap.add_argument("--no-solve-priority", action="store_true",
                     help="testing: EnvConfig.solve_priority=False (the solve launch leaves the wave priority alone)")
+    ap.add_argument("--solver", default="auto", choices=["auto", "direct", "lanczos"],
+                    help="testing: EnvConfig.lambda2_solver (auto: Lanczos iteration from 48 envs per CU on, else the direct solver)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
@@ -242,7 +244,8 @@ def main():
         torch.cuda.synchronize()
 
     cfg = EnvConfig.fast_preset(N=N_ENEMY, M=M_JAM, recluster=not cfgd["reward_only"],
-                                step_schedule=args.schedule, solve_priority=not args.no_solve_priority)
+                                step_schedule=args.schedule, solve_priority=not args.no_solve_priority,
+                                lambda2_solver=args.solver)
     extra = {}
     if args.config == 5:
         from marl_amd.trainer import BatchedTrainer

@@ -52,6 +52,15 @@ extern "C" {
 #define MARL_SCHEDULE_AUTO 0            /* fused for N <= 16 or fewer than 1024 envs, split otherwise */
 #define MARL_SCHEDULE_FUSED 1
 #define MARL_SCHEDULE_SPLIT 2
+/* Solver selectors, added to a `rounds` / lambda2_rounds value (at most one of them).  lambda2 = N - mu_max of the
+ * complement graph's Laplacian; mu_max comes from a direct solver (Householder tridiagonalisation + Sturm
+ * multisection) or, for eigenproblems of 33 to 64 vertices, from a Lanczos iteration that ends when the residual
+ * bound on its largest Ritz value is below 1e-6 max(1, lambda2) (the direct solver takes over if it does not get
+ * there in 64 steps).  With neither selector marl_env_step chooses by the batch: the iteration from 48 envs per
+ * compute unit on, where the launch is bound by the sum of its solves and not by its longest one;
+ * marl_lambda2_from_bits, the reset and the one-launch (fused) step take the direct solver. */
+#define MARL_LAMBDA2_DIRECT 0x100
+#define MARL_LAMBDA2_LANCZOS 0x200
 #define MARL_STAGE_NO_RECLUSTER 1        /* marl_env_step leaves the K_recompute re-clustering (jammer_env.py:394-402) out:
                                            the cluster table of the last reset stays; with MarlStepIO.obs = NULL this is the
                                            "step + reward only" form of the step */
@@ -78,7 +87,7 @@ typedef struct MarlEnvParams {
     int32_t max_steps, K_recompute, min_samples;
     int32_t random_jammer_start;
     int32_t max_reset_attempts;
-    int32_t lambda2_rounds;          /* multisection rounds of the eigenvalue search (0 = default) */
+    int32_t lambda2_rounds;          /* multisection rounds of the eigenvalue search (0 = default), + a MARL_LAMBDA2_* selector */
     int32_t enemy_mode;              /* MARL_ENEMY_RANDOM_WALK or MARL_ENEMY_COORDINATED_TURN (jammer_env.py:103) */
     int32_t step_schedule;           /* N <= 64: MARL_SCHEDULE_AUTO, _FUSED (one launch, solve inside the wave that
                                         stepped the env) or _SPLIT (three launches, longest solve first) */

@@ -580,6 +580,7 @@ __device__ __forceinline__ double column_of(const double (&a)[NPAD], int i) {
 template <bool ON>
 struct SolvePriority {
     int left, level, scale;       // scale: the work of the largest solve, the measure of the levels
+    bool boosted = false;
     static __device__ __forceinline__ void set(int lv) {
         if (lv == 3) __builtin_amdgcn_s_setprio(3);
         else if (lv == 2) __builtin_amdgcn_s_setprio(2);
@@ -595,6 +596,7 @@ struct SolvePriority {
     // `total`: the work the wave has before it, this solve included (a wave of the per-CU launch knows its list);
     // `top`: the work of the largest solve the launch can hold
     __device__ __forceinline__ void start(int total, int top) {
+        if (boosted) return;
         if constexpr (ON) {
             left = total;
             scale = top > 16 ? top : 16;
@@ -606,8 +608,17 @@ struct SolvePriority {
     // (45 / 24 / 11, 35 / 20 / 10 and 20 / 9 / 3 are within 1 % of it).
     // (Alternating between neighbouring levels from step to step, for a priority that follows the work continuously,
     // slowed every wave down by half: priority changes are not free.)
+    // A solve that turns out longer than its size promised (a Lanczos iteration that has not converged at its first
+    // check) goes to the top level and stays there, whether or not the launch otherwise schedules by priority: what it
+    // has left is the launch's critical path.
+    __device__ __forceinline__ void boost() {
+        if (!boosted) __builtin_amdgcn_s_setprio(3);
+        boosted = true;
+        level = 3;
+    }
     __device__ __forceinline__ void spend(int cost) {
         if constexpr (!ON) return;
+        if (boosted) return;
         left -= cost;
         const int x = left * 100;
         const int lv = x >= SOLVE_PRIO_T3 * scale ? 3 : x >= SOLVE_PRIO_T2 * scale ? 2 : x >= SOLVE_PRIO_T1 * scale ? 1 : 0;
@@ -617,17 +628,66 @@ struct SolvePriority {
         }
     }
     __device__ __forceinline__ void finish() {
-        if constexpr (ON) {
-            if (level != 0) __builtin_amdgcn_s_setprio(0);
-            level = 0;
-        }
+        if (boosted || (ON && level != 0)) __builtin_amdgcn_s_setprio(0);
+        level = 0;
+        boosted = false;
     }
 };
 
+// Number of eigenvalues below x of the symmetric tridiagonal matrix de[k] = (d_k, e_k^2), k < np (e_k couples rows
+// k - 1 and k): the sign changes of the Sturm sequence p_0 = 1, p_k = (d_k - x) p_{k-1} - e_k^2 p_{k-2}.
+// AHEAD: 16-byte LDS reads in flight, 8 or 4 (4 registers each; the Lanczos solver's checks run beside more live state
+// than the direct solver's search and take 4).
+template <int AHEAD = 8>
+__device__ __forceinline__ int sturm_count_below(const double2* de, int np, double x) {
+    // The signs of p_1, p_2, ... are shifted into a 32-bit register (one v_alignbit_b32 per term);
+    // with `fresh` new bits at the bottom, the sign changes they add are the set bits
+    // 0..fresh-1 of B ^ (B >> 1) (bit `fresh` is the sign before them; p_0 = 1 is a zero bit).
+    // Flushed before more than 31 are fresh.
+    double pm = 1.0, pc = de[0].x - x;
+    uint32_t bits = (uint32_t)__double2hiint(pc) >> 31;
+    int cnt = 0, fresh = 1;
+    auto term = [&](int i) {
+        const double2 t = de[i];
+        const double pn = fma(t.x - x, pc, -(t.y * pm));
+        bits = __builtin_amdgcn_alignbit(bits, (uint32_t)__double2hiint(pn), 31);
+        pm = pc;
+        pc = pn;
+    };
+    auto flush = [&]() {
+        cnt += __popc((bits ^ (bits >> 1)) & ((1u << fresh) - 1u));
+        fresh = 0;
+    };
+    int i = 1;
+    for (; i + 8 <= np; i += 8) {
+        if constexpr (AHEAD < 8) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) term(i + k);
+            asm volatile("" ::: "memory");          // the second four reads are not issued before the first four terms are done
+#pragma unroll
+            for (int k = 4; k < 8; ++k) term(i + k);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) term(i + k);
+        }
+        fresh += 8;
+        if (fresh >= 17) flush();
+        // keep the recurrence inside the exponent range: a term grows or shrinks the pair by at most
+        // |d - x| + e^2 < 2^18 (np <= 208), so every second block of 8 is often enough
+        if (i & 8) {
+            const int ex = __builtin_amdgcn_frexp_exp(fabs(pc) > fabs(pm) ? pc : pm);
+            pc = ldexp(pc, -ex);
+            pm = ldexp(pm, -ex);
+        }
+    }
+    for (; i < np; ++i) { term(i); ++fresh; }
+    flush();
+    return cnt;
+}
+
 // Sturm multisection for the largest eigenvalue of the symmetric tridiagonal matrix
-// (L.de[k] = (d_k, e_k^2), k < np) inside [lo, hi]: lane t evaluates the Sturm sequence
-// p_0 = 1, p_k = (d_k - x) p_{k-1} - e_k^2 p_{k-2} at x_t; its sign changes count the
-// eigenvalues below x_t.  Every round shrinks the bracket 65-fold.
+// (L.de[k] = (d_k, e_k^2), k < np) inside [lo, hi]: lane t counts the eigenvalues below x_t.
+// Every round shrinks the bracket 65-fold.
 template <class LDS, bool PRIO = false>
 __device__ __forceinline__ double sturm_largest_wave(const LDS& L, int np, int lane, double lo, double hi, int rounds,
                                                      SolvePriority<PRIO>* prio = nullptr) {
@@ -636,40 +696,7 @@ __device__ __forceinline__ double sturm_largest_wave(const LDS& L, int np, int l
         if (prio) prio->spend(4 * np);
         const double w = (hi - lo) * (1.0 / 65.0);
         const double x = lo + w * (double)(lane + 1);
-        // The signs of p_1, p_2, ... are shifted into a 32-bit register (one v_alignbit_b32 per term);
-        // with `fresh` new bits at the bottom, the sign changes they add are the set bits
-        // 0..fresh-1 of B ^ (B >> 1) (bit `fresh` is the sign before them; p_0 = 1 is a zero bit).
-        // Flushed before more than 31 are fresh.
-        double pm = 1.0, pc = L.de[0].x - x;
-        uint32_t bits = (uint32_t)__double2hiint(pc) >> 31;
-        int cnt = 0, fresh = 1;
-        auto term = [&](int i) {
-            const double2 t = L.de[i];
-            const double pn = fma(t.x - x, pc, -(t.y * pm));
-            bits = __builtin_amdgcn_alignbit(bits, (uint32_t)__double2hiint(pn), 31);
-            pm = pc;
-            pc = pn;
-        };
-        auto flush = [&]() {
-            cnt += __popc((bits ^ (bits >> 1)) & ((1u << fresh) - 1u));
-            fresh = 0;
-        };
-        int i = 1;
-        for (; i + 8 <= np; i += 8) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) term(i + k);
-            fresh += 8;
-            if (fresh >= 17) flush();
-            // keep the recurrence inside the exponent range: a term grows or shrinks the pair by at most
-            // |d - x| + e^2 < 2^18 (np <= 208), so every second block of 8 is often enough
-            if (i & 8) {
-                const int ex = __builtin_amdgcn_frexp_exp(fabs(pc) > fabs(pm) ? pc : pm);
-                pc = ldexp(pc, -ex);
-                pm = ldexp(pm, -ex);
-            }
-        }
-        for (; i < np; ++i) { term(i); ++fresh; }
-        flush();
+        const int cnt = sturm_count_below(L.de, np, x);
         const uint64_t all = ballot64(cnt >= np);
         if (all == 0) {
             lo = readlane_d(x, WAVE - 1);
@@ -699,8 +726,39 @@ __device__ __forceinline__ double sturm_largest_wave(const LDS& L, int np, int l
 #else
 #define TSTAMP(k, pin)
 #endif
-template <int NPAD, class LDS, bool PRIO = false>
-__device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int lane, LDS& L, int rounds) {
+// Row `lane` of the Laplacian of the graph whose adjacency row is `crow`, as NPAD registers: a[c] = -1 where bit c of
+// the row is set, the degree on the diagonal (c == lane: the select mask is the constant 1 << c, spelled out because
+// the compiler would build it with a compare per column).  PINNED: the statements are volatile, so that two builds of
+// the same row in one kernel are not merged into one set of registers.
+template <int NPAD, bool PINNED>
+__device__ __forceinline__ void laplacian_row_registers(uint64_t crow, int cdeg, double (&a)[NPAD]) {
+    const double dg = (double)cdeg;
+    const int dg_hi = __double2hiint(dg), dg_lo = __double2loint(dg);
+    uint32_t w_lo = (uint32_t)crow, w_hi = (uint32_t)(crow >> 32);
+    // (opaque copies of the row words: the bit extractions of two builds are then not shared either - fifty values
+    // kept from the first build for the second would be fifty registers live through whatever lies between)
+    if constexpr (PINNED) asm volatile("" : "+v"(w_lo), "+v"(w_hi));
+    static_for<0, NPAD>([&](auto k) {
+        constexpr int c = decltype(k)::value;
+        int hi = __builtin_amdgcn_sbfe((int)(c < 32 ? w_lo : w_hi), c & 31, 1) & (int)0xBFF00000, lo;
+        const uint64_t diag = 1ull << c;
+        if constexpr (PINNED)
+            asm volatile("v_cndmask_b32_e64 %0, %0, %2, %4\n\tv_cndmask_b32_e64 %1, 0, %3, %4"
+                         : "+v"(hi), "=v"(lo) : "v"(dg_hi), "v"(dg_lo), "s"(diag));
+        else
+            asm("v_cndmask_b32_e64 %0, %0, %2, %4\n\tv_cndmask_b32_e64 %1, 0, %3, %4"
+                : "+v"(hi), "=v"(lo) : "v"(dg_hi), "v"(dg_lo), "s"(diag));
+        a[c] = __hiloint2double(hi, lo);
+    });
+}
+
+#include "lanczos_solve.inc"
+
+// `rounds`: multisection rounds of the eigenvalue search.  LANCZOS: problems of at least LANCZOS_MIN_NP vertices go
+// through the Lanczos iteration first (the direct solver below takes over if it does not meet its bound).
+// nfull: vertices of the whole graph (lambda2 = nfull - mu_max scales the Lanczos tolerance).
+template <int NPAD, class LDS, bool PRIO = false, bool LANCZOS = false>
+__device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int lane, LDS& L, int rounds, double nfull) {
     const int cdeg = __popcll(crow);
     int dmax = cdeg;
     dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, 0x128, 0xF, 0xF, false));      // row_ror:8, 4, 2, 1
@@ -711,22 +769,27 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
                max(__builtin_amdgcn_readlane(dmax, 32), __builtin_amdgcn_readlane(dmax, 48)));
 
     constexpr int KB = (NPAD + 15) / 16;
-    double a[NPAD];                                   // row `lane` of the matrix
-    // a[c] = -1 where bit c of the row is set, the degree on the diagonal (c == lane: the select mask is the
-    // constant 1 << c, spelled out because the compiler would build it with a compare per column)
-    {
-        const double dg = (double)cdeg;
-        const int dg_hi = __double2hiint(dg), dg_lo = __double2loint(dg);
-        const uint32_t w_lo = (uint32_t)crow, w_hi = (uint32_t)(crow >> 32);
-        static_for<0, NPAD>([&](auto k) {
-            constexpr int c = decltype(k)::value;
-            int hi = __builtin_amdgcn_sbfe((int)(c < 32 ? w_lo : w_hi), c & 31, 1) & (int)0xBFF00000, lo;
-            const uint64_t diag = 1ull << c;
-            asm("v_cndmask_b32_e64 %0, %0, %2, %4\n\tv_cndmask_b32_e64 %1, 0, %3, %4"
-                : "+v"(hi), "=v"(lo) : "v"(dg_hi), "v"(dg_lo), "s"(diag));
-            a[c] = __hiloint2double(hi, lo);
-        });
+    SolvePriority<PRIO> prio;
+    if constexpr (LANCZOS) {
+        if (np >= LANCZOS_MIN_NP) {
+            prio.start(lanczos_work(np), lanczos_work(NPAD));
+            double mu;
+            // (the iteration works on a register matrix of its own, built a second time below if the direct solver has to
+            // take over, which is rare: one set of registers live through both solvers costs the kernel a wave per SIMD)
+            if (mu_max_lanczos_wave<NPAD, LDS, PRIO>(crow, cdeg, np, lane, dmax, nfull, L, rounds, prio, mu)) {
+                prio.finish();
+                return mu;
+            }
+#ifdef MARL_EXP_LANCZOS_STATS
+            return nfull - 10000.0;
+#endif
+        }
+        prio.start(SolvePriority<PRIO>::work(np, rounds), lanczos_work(NPAD));
+    } else {
+        prio.start(SolvePriority<PRIO>::work(np, rounds), SolvePriority<PRIO>::work(NPAD, rounds));
     }
+    double a[NPAD];                                   // row `lane` of the matrix
+    laplacian_row_registers<NPAD, LANCZOS>(crow, cdeg, a);
 
 #ifdef MARL_EXP_TIMING
     double tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -735,8 +798,6 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
 #endif
     // pivot column A[lane][i]: the first one from the bits, the later ones handed back by the update
     double col = (lane == np - 1) ? (double)cdeg : -(double)((crow >> (np - 1)) & 1ull);
-    SolvePriority<PRIO> prio;
-    prio.start(SolvePriority<PRIO>::work(np, rounds), SolvePriority<PRIO>::work(NPAD, rounds));
     for (int i = np - 1; i >= 2; --i) {
         const int l = i - 1;
         prio.spend(85 + 3 * i);
@@ -947,13 +1008,13 @@ __device__ __forceinline__ double mu_max_pair_wave(uint32_t crow, int np, int np
 // mu_max of one eigenproblem inside a wave, by the solver the step's solve launch would use for it: problems of
 // at most 32 vertices go through the two-per-wave code (alone, the upper half idle), so that the result does not
 // depend on the schedule; larger ones through the 64-lane solver.
-template <int NPAD, class LDS>
-__device__ __forceinline__ double mu_max_in_wave(uint64_t crow, int np, int lane, LDS& L, int rounds) {
+template <int NPAD, class LDS, bool LANCZOS = false>
+__device__ __forceinline__ double mu_max_in_wave(uint64_t crow, int np, int lane, LDS& L, int rounds, double nfull) {
     if (np <= 32) {
         const bool upper = lane >= 32;
         return readlane_d(mu_max_pair_wave(upper ? 0u : (uint32_t)crow, np, upper ? 0 : np, lane, L, rounds + 2), 0);
     }
-    if constexpr (NPAD > 32) return mu_max_compact_wave<NPAD>(crow, np, lane, L, rounds);
+    if constexpr (NPAD > 32) return mu_max_compact_wave<NPAD, LDS, false, LANCZOS>(crow, np, lane, L, rounds, nfull);
     return 0.0;
 }
 
@@ -1008,13 +1069,13 @@ __device__ __forceinline__ bool lambda2_prepare(uint64_t row, int n, int lane, W
     return false;
 }
 
-template <int NPAD>
+template <int NPAD, bool LANCZOS = false>
 __device__ __forceinline__ double lambda2_wave(uint64_t row, int n, int lane, WaveLds& L, int rounds) {
     double lam;
     uint64_t crow;
     int np;
     if (lambda2_prepare(row, n, lane, L, lam, crow, np)) return lam;
-    return (double)n - mu_max_in_wave<NPAD>(crow, np, lane, L, rounds);
+    return (double)n - mu_max_in_wave<NPAD, WaveLds, LANCZOS>(crow, np, lane, L, rounds, (double)n);
 }
 
 // ------------------------------------------------------------------ DBSCAN + centroids
@@ -1436,7 +1497,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 
     bool final_lam = lambda2_prepare(adj & ~jam, n, lane, L, lam, crow, np);
     if constexpr (FUSED > 0) {
         if (!final_lam) {
-            lam = (double)n - mu_max_in_wave<FUSED>(crow, np, lane, L, P.lambda2_rounds);
+            lam = (double)n - mu_max_in_wave<FUSED>(crow, np, lane, L, P.lambda2_rounds, (double)n);
             final_lam = true;
             np = 0;
         }
@@ -1543,7 +1604,7 @@ struct SolveLds {
 // Work item `item` of a step's solve launch, by one wave: the items are the pending eigenproblems in the order of
 // solve_perm (largest first).  The problems of more than 32 vertices are an item each (items 0..nbig-1), the others
 // share one in pairs.  The wave then finishes the reward of the env (or the two).
-template <int NPAD, bool PRIO>
+template <int NPAD, bool PRIO, bool LANCZOS>
 __device__ __forceinline__ void solve_item(const MarlEnvParams& P, const MarlEnvState& S, const MarlStepIO& io, int item,
                                            int nbig, int total, int lane, SolveLds& L) {
     BT_BEGIN();
@@ -1572,7 +1633,7 @@ __device__ __forceinline__ void solve_item(const MarlEnvParams& P, const MarlEnv
     const int e = S.solve_perm[item];
     const int np = S.solve_np[e];
     const uint64_t crow = (lane < np) ? S.solve_rows[(size_t)e * WAVE + lane] : 0ull;
-    const double lam = (double)P.N - mu_max_compact_wave<NPAD, SolveLds, PRIO>(crow, np, lane, L, P.lambda2_rounds);
+    const double lam = (double)P.N - mu_max_compact_wave<NPAD, SolveLds, PRIO, LANCZOS>(crow, np, lane, L, P.lambda2_rounds, (double)P.N);
     if (lane == 0) {
         const double* part = S.solve_partial + (size_t)e * 4;
         double r1;
@@ -1587,7 +1648,7 @@ __device__ __forceinline__ void solve_item(const MarlEnvParams& P, const MarlEnv
 }
 
 // Solve, one wave per workgroup: block b takes item b.
-template <int NPAD, bool PRIO>
+template <int NPAD, bool PRIO, bool LANCZOS = false>
 __device__ __forceinline__ void solve_block(const MarlEnvParams& P, const MarlEnvState& S, const MarlStepIO& io) {
     __shared__ SolveLds L;
     const int lane = threadIdx.x;
@@ -1601,7 +1662,7 @@ __device__ __forceinline__ void solve_block(const MarlEnvParams& P, const MarlEn
             for (int k = lane; k < SOLVE_HIST_TOTAL; k += WAVE) S.solve_hist[k] = 0;
         return;
     }
-    solve_item<NPAD, PRIO>(P, S, io, (int)blockIdx.x, nbig, total, lane, L);
+    solve_item<NPAD, PRIO, LANCZOS>(P, S, io, (int)blockIdx.x, nbig, total, lane, L);
 }
 template <int NPAD>
 __global__ __launch_bounds__(WAVE) void env_step_solve_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
@@ -1612,6 +1673,14 @@ __global__ __launch_bounds__(WAVE) void env_step_solve_kernel(MarlEnvParams P, M
 template <int NPAD>
 __global__ __launch_bounds__(WAVE) void env_step_solve_prio_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
     solve_block<NPAD, true>(P, S, io);
+}
+// The same with the problems of more than 32 vertices going through the Lanczos iteration first (lanczos_solve.inc).
+// Three waves per SIMD: the iteration needs about 165 registers at 50 columns (the register matrix, the vectors in
+// both forms, the reads of an eigenvalue search in flight), where the direct solver alone fits four waves -- which is
+// why it is a kernel of its own and not a branch of the one above.
+template <int NPAD>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 8))) void env_step_solve_lanczos_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
+    solve_block<NPAD, false, true>(P, S, io);
 }
 
 // ------------------------------------------------------------------ reset kernel (N <= 64)
@@ -1763,8 +1832,8 @@ __global__ __launch_bounds__(WAVE) void jam_bits_kernel(MarlEnvParams P, const d
     store_bits(bits, e, n, lane, jam_row(L, n, m, lane, b, P.jam_d2_max[b]));
 }
 
-template <int NPAD>
-__global__ __launch_bounds__(WAVE) void lambda2_bits_kernel(int n, const uint32_t* bits, double* lambda2, int rounds) {
+template <int NPAD, bool LANCZOS>
+__device__ __forceinline__ void lambda2_bits_body(int n, const uint32_t* bits, double* lambda2, int rounds) {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds& L = carve(smem);
     const int e = blockIdx.x, lane = threadIdx.x;
@@ -1777,8 +1846,16 @@ __global__ __launch_bounds__(WAVE) void lambda2_bits_kernel(int n, const uint32_
         row &= ~(1ull << lane);
         if (n < 64) row &= (1ull << n) - 1;
     }
-    const double lam = lambda2_wave<NPAD>(row, n, lane, L, rounds);
+    const double lam = lambda2_wave<NPAD, LANCZOS>(row, n, lane, L, rounds);
     if (lane == 0) lambda2[e] = lam;
+}
+template <int NPAD>
+__global__ __launch_bounds__(WAVE) void lambda2_bits_kernel(int n, const uint32_t* bits, double* lambda2, int rounds) {
+    lambda2_bits_body<NPAD, false>(n, bits, lambda2, rounds);
+}
+template <int NPAD>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 8))) void lambda2_bits_lanczos_kernel(int n, const uint32_t* bits, double* lambda2, int rounds) {
+    lambda2_bits_body<NPAD, true>(n, bits, lambda2, rounds);
 }
 
 __global__ __launch_bounds__(WAVE) void dbscan_kernel(MarlEnvParams P, const double* x, const double* y,
@@ -2221,7 +2298,7 @@ __device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int 
     WSYNC();
     if (np <= WAVE) {
         const uint64_t crow = (lane < np) ? L.xfer[lane * S] : 0ull;
-        return (double)n - mu_max_in_wave<WAVE>(crow, np, lane, L, rounds);
+        return (double)n - mu_max_in_wave<WAVE>(crow, np, lane, L, rounds, (double)n);
     }
     if (pending != nullptr && np <= TEAM_MAX_NP) {
         unsigned long long* out = reinterpret_cast<unsigned long long*>(As);
@@ -3079,6 +3156,16 @@ int static_scratch(void** out) {
     return MARL_OK;
 }
 
+// A `rounds` value: multisection rounds in the low byte (0 = the default, 8) plus at most one solver selector.
+int check_rounds(int32_t* rounds) {
+    const int32_t sel = *rounds & (MARL_LAMBDA2_DIRECT | MARL_LAMBDA2_LANCZOS);
+    if (*rounds < 0 || (*rounds & ~(0xFF | MARL_LAMBDA2_DIRECT | MARL_LAMBDA2_LANCZOS)) ||
+        sel == (MARL_LAMBDA2_DIRECT | MARL_LAMBDA2_LANCZOS))
+        return MARL_EINVAL;
+    if ((*rounds & 0xFF) == 0) *rounds |= 8;
+    return MARL_OK;
+}
+
 int check_sizes(const MarlEnvParams* p) {
     if (p == nullptr) return MARL_EINVAL;
     if (p->N < 1 || p->M < 1) return MARL_EINVAL;
@@ -3097,6 +3184,10 @@ size_t workspace_bytes(int N, int E) {
 
 
 // Team solver launch: 104 columns per thread beyond 128 vertices, 64 up to there.
+#ifdef MARL_DEV_FAST      /* development builds leave the kernels for N > 64 out */
+#define MARL_LAUNCH_TEAM(N, kern, E, stream, ...) do { } while (0)
+#define MARL_DISPATCH_SLOTS(N, kern, grid, stream, ...) do { } while (0)
+#else
 #define MARL_LAUNCH_TEAM(N, kern, E, stream, ...)                                                                   \
     do {                                                                                                            \
         const int s_ = ((N) + WAVE - 1) / WAVE;                                                                     \
@@ -3111,11 +3202,15 @@ size_t workspace_bytes(int N, int E) {
         case 3: hipLaunchKernelGGL((kern<3>), grid, dim3(WAVE), sizeof(BigLds<3>), (hipStream_t)(stream), __VA_ARGS__); break; \
         default: hipLaunchKernelGGL((kern<4>), grid, dim3(WAVE), sizeof(BigLds<4>), (hipStream_t)(stream), __VA_ARGS__); break; \
     }
+#endif
 
 // The wave kernels are instantiated per register-matrix width NPAD = N rounded up to 8, and for 50 (the
 // reference's standard swarm: 12 registers fewer than 56 make room for a fourth wave per SIMD).
 #define MARL_LAUNCH_NPAD(NP, kern, grid, lds, stream, ...) \
     hipLaunchKernelGGL((kern<NP>), grid, dim3(WAVE), lds, (hipStream_t)(stream), __VA_ARGS__)
+#ifdef MARL_DEV_FAST      /* development builds: the 50-column kernels only (compiles in a fraction of the time) */
+#define MARL_DISPATCH_NPAD(N, kern, grid, lds, stream, ...) MARL_LAUNCH_NPAD(50, kern, grid, lds, stream, __VA_ARGS__)
+#else
 #define MARL_DISPATCH_NPAD(N, kern, grid, lds, stream, ...)                                   \
     if ((N) > 48 && (N) <= 50) {                                                               \
         MARL_LAUNCH_NPAD(50, kern, grid, lds, stream, __VA_ARGS__);                            \
@@ -3129,6 +3224,31 @@ size_t workspace_bytes(int N, int E) {
         case 7: MARL_LAUNCH_NPAD(56, kern, grid, lds, stream, __VA_ARGS__); break;             \
         default: MARL_LAUNCH_NPAD(64, kern, grid, lds, stream, __VA_ARGS__); break;            \
     }
+#endif
+
+// The kernels with the Lanczos iteration exist for swarms of more than 32 enemies only (smaller eigenproblems all go to
+// the two-per-wave direct solver).
+#ifdef MARL_DEV_FAST
+#define MARL_DISPATCH_NPAD_BIG(N, kern, grid, lds, stream, ...) MARL_LAUNCH_NPAD(50, kern, grid, lds, stream, __VA_ARGS__)
+#else
+#define MARL_DISPATCH_NPAD_BIG(N, kern, grid, lds, stream, ...)                               \
+    if ((N) > 48 && (N) <= 50) {                                                               \
+        MARL_LAUNCH_NPAD(50, kern, grid, lds, stream, __VA_ARGS__);                            \
+    } else switch (((N) + 7) / 8) {                                                            \
+        case 5: MARL_LAUNCH_NPAD(40, kern, grid, lds, stream, __VA_ARGS__); break;             \
+        case 6: MARL_LAUNCH_NPAD(48, kern, grid, lds, stream, __VA_ARGS__); break;             \
+        case 7: MARL_LAUNCH_NPAD(56, kern, grid, lds, stream, __VA_ARGS__); break;             \
+        default: MARL_LAUNCH_NPAD(64, kern, grid, lds, stream, __VA_ARGS__); break;            \
+    }
+#endif
+
+// The Lanczos iteration halves the instructions of a large eigen-solve on average, at three waves per SIMD instead of four
+// and with a spread of 1 : 2 between the fastest and the slowest solve of one size that the launch order cannot foresee.
+// A launch that the chip holds in about one round of waves is as long as its slowest solve, and the direct solver's are all
+// alike: 8 192 envs x (50, 8) on 256 CUs take 0.110 ms per step with it and 0.118 ms with the iteration (4 096 envs: 0.077
+// against 0.090).  Batches of several rounds are bound by the sum instead: 16 384 envs 0.191 against 0.167 ms.  AUTO
+// therefore takes the iteration from 48 envs per CU on.
+enum { LANCZOS_AUTO_ENVS_PER_CU = 48 };
 
 // Priorities in the solve launch pay when the launch is about one round of the chip's wave slots (16 per CU; about 0.6
 // solve blocks per env): every slot then starts a solve at once and nothing follows, so what counts is that the four
@@ -3210,7 +3330,7 @@ int marl_params_init(MarlEnvParams* p) {
     p->v_max_f32 = (float)p->v_max;
     p->v_max_sq_f32 = (float)(p->v_max * p->v_max);
     if (p->stage_flags & ~(MARL_STAGE_NO_RECLUSTER | MARL_STAGE_NO_SOLVE_PRIORITY)) return MARL_EINVAL;
-    if (p->lambda2_rounds <= 0) p->lambda2_rounds = 8;
+    if (check_rounds(&p->lambda2_rounds) != MARL_OK) return MARL_EINVAL;
     return MARL_OK;
 }
 
@@ -3312,6 +3432,10 @@ int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepI
     if (s->E < 1 || io->actions == nullptr || io->reward == nullptr ||
         io->truncated == nullptr || s->enemy_x == nullptr || s->episode_return == nullptr)
         return MARL_EINVAL;
+    const int solver = p->lambda2_rounds & (MARL_LAMBDA2_DIRECT | MARL_LAMBDA2_LANCZOS);
+    MarlEnvParams q = *p;
+    q.lambda2_rounds &= 0xFF;                  // the kernels take the plain number of rounds
+    p = &q;
     if (p->N > WAVE) {
         if (s->workspace == nullptr || s->solve_partial == nullptr) return MARL_EINVAL;
         MARL_DISPATCH_SLOTS(p->N, env_step_big_kernel, dim3(s->E), stream, *p, *s, *io);
@@ -3330,8 +3454,13 @@ int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepI
     hipLaunchKernelGGL(env_step_front_kernel<0>, dim3(s->E), dim3(WAVE), front_lds_bytes(), (hipStream_t)stream, *p, *s, *io);
     hipLaunchKernelGGL(solve_order_kernel, dim3((s->E + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, (int)s->E, *s);
     // one block more than envs: the last one never has a solve and clears the histogram
-    const int cus = (p->stage_flags & MARL_STAGE_NO_SOLVE_PRIORITY) ? 0 : cu_count();
-    if (cus > 0 && s->E >= SOLVE_PRIORITY_ENVS_PER_CU_MIN * cus && s->E <= SOLVE_PRIORITY_ENVS_PER_CU_MAX * cus) {
+    const int all_cus = cu_count();
+    const bool lanczos = p->N > 32 && (solver == MARL_LAMBDA2_LANCZOS ||
+                                       (solver == 0 && all_cus > 0 && s->E >= LANCZOS_AUTO_ENVS_PER_CU * all_cus));
+    const int cus = (p->stage_flags & MARL_STAGE_NO_SOLVE_PRIORITY) ? 0 : all_cus;
+    if (lanczos) {
+        MARL_DISPATCH_NPAD_BIG(p->N, env_step_solve_lanczos_kernel, dim3(s->E + 1), 0, stream, *p, *s, *io);
+    } else if (cus > 0 && s->E >= SOLVE_PRIORITY_ENVS_PER_CU_MIN * cus && s->E <= SOLVE_PRIORITY_ENVS_PER_CU_MAX * cus) {
         MARL_DISPATCH_NPAD(p->N, env_step_solve_prio_kernel, dim3(s->E + 1), 0, stream, *p, *s, *io);
     } else {
         MARL_DISPATCH_NPAD(p->N, env_step_solve_kernel, dim3(s->E + 1), 0, stream, *p, *s, *io);
@@ -3345,6 +3474,9 @@ int marl_env_reset(const MarlEnvParams* p, const MarlEnvState* s, const MarlRese
     if (rc != MARL_OK) return rc;
     if (s->E < 1 || s->enemy_x == nullptr) return MARL_EINVAL;
     if ((io->enemy_pos == nullptr) != (io->enemy_vel == nullptr)) return MARL_EINVAL;
+    MarlEnvParams q = *p;
+    q.lambda2_rounds &= 0xFF;                  // the reset's lambda2 (of the unjammed graph) is the direct solver's
+    p = &q;
     if (p->N > WAVE) {
         if (s->workspace == nullptr) return MARL_EINVAL;
         MARL_DISPATCH_SLOTS(p->N, env_reset_big_kernel, dim3(s->E), stream, *p, *s, *io);
@@ -3464,7 +3596,9 @@ int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t* bits, double* l
         if (workspace == nullptr) return MARL_EINVAL;
         return hip_check((hipError_t)marl_lambda2_large_launch(N, E, bits, lambda2, (double*)workspace, stream));
     }
-    if (rounds <= 0) rounds = 8;
+    if (check_rounds(&rounds) != MARL_OK) return MARL_EINVAL;
+    const bool lanczos = (rounds & MARL_LAMBDA2_LANCZOS) != 0;       // the stage op takes the direct solver unless asked
+    rounds &= 0xFF;
     if (N > WAVE) {
         if (workspace == nullptr) return MARL_EINVAL;
         int* pend = workspace_pending((double*)workspace, N, E);
@@ -3475,7 +3609,11 @@ int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t* bits, double* l
                          ld * ld, lambda2, (int)rounds);
         return hip_check(hipGetLastError());
     }
-    MARL_DISPATCH_NPAD(N, lambda2_bits_kernel, dim3(E), wave_lds_bytes(N), stream, (int)N, bits, lambda2, (int)rounds);
+    if (lanczos && N > 32) {
+        MARL_DISPATCH_NPAD_BIG(N, lambda2_bits_lanczos_kernel, dim3(E), wave_lds_bytes(N), stream, (int)N, bits, lambda2, (int)rounds);
+    } else {
+        MARL_DISPATCH_NPAD(N, lambda2_bits_kernel, dim3(E), wave_lds_bytes(N), stream, (int)N, bits, lambda2, (int)rounds);
+    }
     return hip_check(hipGetLastError());
 }
 

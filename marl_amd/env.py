@@ -62,6 +62,7 @@ class EnvConfig:
     step_schedule: str = "auto"     # N <= 64: "auto", "fused" (one launch per step) or "split" (three, longest solve first)
     recluster: bool = True          # False: step() never re-clusters (the table of the last reset stays): "step + reward only"
     solve_priority: bool = True     # split schedule: the issue priority of an eigen-solve follows the work it has left
+    lambda2_solver: str = "auto"    # split schedule, N > 32: "direct" (Householder), "lanczos" (iteration first), or by the batch size
 
     @staticmethod
     def fast_preset(N: int = 10, M: int = 4, **kw) -> "EnvConfig":
@@ -82,7 +83,8 @@ class EnvConfig:
         p.max_steps, p.K_recompute, p.min_samples = int(self.max_steps), int(self.K_recompute), int(self.min_samples)
         p.random_jammer_start = int(bool(self.random_jammer_start))
         p.max_reset_attempts = int(self.max_reset_attempts)
-        p.lambda2_rounds = int(self.lambda2_rounds)
+        p.lambda2_rounds = int(self.lambda2_rounds) | {"auto": 0, "direct": _lib.LAMBDA2_DIRECT,
+                                                       "lanczos": _lib.LAMBDA2_LANCZOS}[self.lambda2_solver]
         p.stage_flags = (0 if self.recluster else _lib.STAGE_NO_RECLUSTER) | (0 if self.solve_priority else _lib.STAGE_NO_SOLVE_PRIORITY)
         p.arena_size, p.dt, p.v_max, p.v_enemy = float(self.arena_size), float(self.dt), float(self.v_max), float(self.v_enemy)
         p.P_tx_w, p.P_sens_w = db_to_watts(self.P_tx_dbm), db_to_watts(self.P_sens_dbm)
@@ -415,7 +417,7 @@ class BatchedJammerEnv:
             nb = self.lib.marl_lambda2_workspace_bytes(self.N, self.E)
             ws = torch.empty(nb, dtype=torch.uint8, device=self.device) if nb else None
             _lib.check(self.lib.marl_lambda2_from_bits(self.N, self.E, adj.data_ptr(), out.data_ptr(),
-                                                       self.params.lambda2_rounds, _ptr(ws), _stream()),
+                                                       self.params.lambda2_rounds & 0xFF, _ptr(ws), _stream()),
                        "marl_lambda2_from_bits")
         return out
 

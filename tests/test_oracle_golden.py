@@ -278,3 +278,18 @@ def test_reset_retry_loop_matches_reference():
             assert np.array_equal(st.assign.astype(np.int32), r["assign"])
             assert np.array_equal(st.jammer_positions, r["jpos"])
             np.testing.assert_allclose(obs, r["obs"], rtol=1e-6, atol=1e-7)
+
+
+def test_lambda2_beyond_256_vertices_against_the_reference_branches():
+    """tests/golden/lambda2_sparse.npz: the reference's dense and sparse branches of compute_lambda2
+    (communication_graph.py:268-286) on graphs of 300 to 1 024 vertices.  The oracle follows the dense branch
+    (the one the env takes); on connected graphs the sparse branch gives the same value."""
+    z = gu.load("lambda2_sparse.npz")
+    for k in range(int(z["n_graphs"])):
+        n = int(z[f"g{k}_n"])
+        A = orc.unpack_rows(z[f"g{k}_adj"], n)
+        lam = orc.lambda2_of_laplacian(orc.laplacian(A))
+        dense, sparse = float(z[f"g{k}_lam_dense"]), float(z[f"g{k}_lam_sparse"])
+        assert abs(lam - dense) <= 1e-12 * max(1.0, abs(dense))
+        if abs(dense) > 1e-9:
+            assert abs(lam - sparse) <= 1e-9 * max(1.0, abs(sparse))
