@@ -113,8 +113,10 @@ def cpu_baseline(N, M, seconds=8.0):
 
 
 def profile_summary(cfg_id):
-    """Counter-derived figures of the committed rocprofv3 runs of this same command (profiles/): HBM bytes per
-    step, VALU busy %, average duration of the eigen-solve kernel.  None where no profile was taken."""
+    """Figures of the committed rocprofv3 runs of this same command (profiles/summary_c<n>.json): HBM bytes per step
+    and VALU busy % from the counter passes, average kernel durations from the kernel trace, and the commit they were
+    taken at.  They are NOT measured by this run and are reported under `profile` with their origin.  {} where no
+    profile was taken."""
     path = os.path.join(ROOT, "profiles", f"summary_c{cfg_id}.json")
     if not os.path.exists(path):
         return {}
@@ -122,6 +124,19 @@ def profile_summary(cfg_id):
         return json.load(open(path))
     except Exception:
         return {}
+
+
+def solve_launch_time(env, pool, first, reps=32):
+    """The launch that holds the eigen-solves, live: `reps` more steps of `env` (one launch sequence) through
+    marl_env_step_timed, which records a HIP event before and after that launch on the launch stream; microseconds
+    per launch (mean, max)."""
+    import torch
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for i, ev in enumerate(pairs):
+        env.step(pool[(first + i) % pool.shape[0]], solve_events=ev)
+    torch.cuda.synchronize()
+    us = [a.elapsed_time(b) * 1e3 for a, b in pairs]
+    return sum(us) / len(us), max(us)
 
 
 def lambda2_stage_time(env, reps=10):
@@ -342,8 +357,9 @@ def main():
             f1.record()
             torch.cuda.synchronize()
             extra["one_stream_ms_per_step"] = f0.elapsed_time(f1) / steps
-            del one
-        env_for_stage = env
+            env_for_stage = one
+        else:
+            env_for_stage = env
     if dist is not None:
         t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)]
@@ -356,6 +372,7 @@ def main():
 
     if rank == 0:
         stage_us = lambda2_stage_time(env_for_stage)
+        solve_us, solve_us_max = solve_launch_time(env_for_stage, pool, 0)
         F = flops_per_env_step(N_ENEMY, M_JAM)
         B = bytes_per_env_step(N_ENEMY, M_JAM)
         achieved_tflops = F * E / (kern_ms * 1e-3) / 1e12
@@ -376,6 +393,8 @@ def main():
                        "envs_per_gpu": E, "N": N_ENEMY, "M": M_JAM, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "valu", "achieved": achieved_tflops, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_VALU_TFLOPS,
+                         # HBM bytes per step: counter passes cannot run inside this process; the figure of the
+                         # committed passes of this command, see `profile` for where it comes from
                          "traffic": prof.get("hbm_bytes_per_step"),
                          "kernel": f"marl_env_step = {sched} (+ the masked reset launch on the steps that need it); "
                                    + (f"the batch in {extra['streams']} parts on streams of their own, whose kernels overlap; "
@@ -385,20 +404,28 @@ def main():
                                       if args.config == 5 else ""),
                          "kernel_ms": kern_ms,
                          "algorithmic_flops_per_env_step": F,
-                         "valu_busy_pct": prof.get("valu_busy_pct"),
                          "hbm": {"algorithmic_bytes_per_env_step": B,
                                  "achieved_GBps": B * E / (kern_ms * 1e-3) / 1e9, "peak_GBps": PEAK_HBM_GBPS,
                                  "frac": B * E / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS}},
             "lambda2_mean": lam_mean,
             "us_per_env_step_kernel": kern_ms * 1e3 / E,
-            # eigen-solve stage: live, the stage op on the jammed graphs of the final state (envs in index
-            # order, connectivity test + complement compaction + solve in one wave); from the committed kernel
-            # trace, the step's own solve launch (longest first)
-            "lambda2_solve_us_per_env": prof.get("solve_kernel_us", stage_us) / E,
+            # Both measured by this run, after the timed region.  Solve launch: HIP events recorded by the library
+            # around the launch of the step that holds the eigen-solves (longest first), 32 further steps.  Stage op:
+            # marl_lambda2_from_bits on the jammed graphs of the final state (envs in index order; connectivity
+            # test + complement compaction + solve in one wave).
+            "lambda2_solve_us_per_env": solve_us / E,
+            "lambda2_solve_launch_us": {"mean": solve_us, "max": solve_us_max, "launches": 32,
+                                        "source": "live: marl_env_step_timed, HIP events on the launch stream"},
             "lambda2_stage_op_us_per_env": stage_us / E,
-            "lambda2_solve_source": "profiles/summary_c%d.json (rocprofv3 kernel trace)" % args.config
-                                    if "solve_kernel_us" in prof else "live stage op",
         }
+        if prof:
+            out["profile"] = {
+                "source": f"profiles/summary_c{args.config}.json: rocprofv3 kernel trace and --pmc passes of "
+                          f"`{prof.get('command', 'python3 bench.py --config %d --shards 1' % args.config)}`, taken at commit "
+                          f"{prof.get('git_head', 'unknown')}; not measured by this run",
+                "hbm_bytes_per_step": prof.get("hbm_bytes_per_step"),
+                "valu_busy_pct": prof.get("valu_busy_pct"),
+                "kernel_avg_us": prof.get("kernel_avg_us")}
         out.update(extra)
         if cpu is not None:
             out["cpu_baseline"] = cpu

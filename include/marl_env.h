@@ -220,6 +220,14 @@ int marl_last_hip_error(void);
  * Laplacian lambda2, 5-term reward, observation. */
 int marl_env_step(const MarlEnvParams *p, const MarlEnvState *s, const MarlStepIO *io, void *stream);
 
+/* Measurement aid (no counterpart in the reference): marl_env_step with two HIP events recorded on `stream`,
+ * `solve_begin` before and `solve_end` after the launch that holds the Laplacian eigen-solves (the third launch
+ * of the three-launch schedule, the wide-team launch for N > 64, the only launch of the one-launch schedule).
+ * Both are hipEvent_t handles created by the caller with timing enabled; their elapsed time is the duration of
+ * that launch on an otherwise idle stream. */
+int marl_env_step_timed(const MarlEnvParams *p, const MarlEnvState *s, const MarlStepIO *io, void *stream,
+                        void *solve_begin, void *solve_end);
+
 /* JammerEnv.reset for the masked envs (environment/jammer_env.py:261-354). */
 int marl_env_reset(const MarlEnvParams *p, const MarlEnvState *s, const MarlResetIO *io, void *stream);
 

@@ -124,6 +124,8 @@ SYMBOLS = {
     "marl_last_hip_error": (C.c_int, []),
     "marl_env_step": (C.c_int, [C.POINTER(MarlEnvParams), C.POINTER(MarlEnvState), C.POINTER(MarlStepIO),
                                 C.c_void_p]),
+    "marl_env_step_timed": (C.c_int, [C.POINTER(MarlEnvParams), C.POINTER(MarlEnvState), C.POINTER(MarlStepIO),
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "marl_env_reset": (C.c_int, [C.POINTER(MarlEnvParams), C.POINTER(MarlEnvState), C.POINTER(MarlResetIO),
                                  C.c_void_p]),
     "marl_adjacency_bits": (C.c_int, [C.POINTER(MarlEnvParams), C.c_int32, _pd, _pd, _pi, _pu32, C.c_void_p]),

@@ -3425,7 +3425,10 @@ int marl_state_shard(const MarlEnvParams* p, const MarlEnvState* whole, int32_t 
     return MARL_OK;
 }
 
-int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepIO* io, void* stream) {
+// The step's launches; with events, `before` and `after` are recorded on the stream around the launch that holds the
+// eigen-solves (the only launch of the one-launch schedule).
+static int step_launches(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepIO* io, void* stream,
+                         hipEvent_t before, hipEvent_t after) {
     if (p == nullptr || s == nullptr || io == nullptr) return MARL_EINVAL;
     int rc = check_sizes(p);
     if (rc != MARL_OK) return rc;
@@ -3439,7 +3442,9 @@ int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepI
     if (p->N > WAVE) {
         if (s->workspace == nullptr || s->solve_partial == nullptr) return MARL_EINVAL;
         MARL_DISPATCH_SLOTS(p->N, env_step_big_kernel, dim3(s->E), stream, *p, *s, *io);
+        if (before != nullptr && (rc = hip_check(hipEventRecord(before, (hipStream_t)stream))) != MARL_OK) return rc;
         MARL_LAUNCH_TEAM(p->N, env_step_team_kernel, s->E, stream, *p, *s, *io);
+        if (after != nullptr && (rc = hip_check(hipEventRecord(after, (hipStream_t)stream))) != MARL_OK) return rc;
         return hip_check(hipGetLastError());
     }
     if (s->solve_rows == nullptr || s->solve_np == nullptr || s->solve_slot == nullptr || s->solve_perm == nullptr ||
@@ -3448,11 +3453,14 @@ int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepI
     const bool fused = p->step_schedule == MARL_SCHEDULE_FUSED ||
                        (p->step_schedule == MARL_SCHEDULE_AUTO && (p->N <= 16 || s->E < 1024));
     if (fused) {
+        if (before != nullptr && (rc = hip_check(hipEventRecord(before, (hipStream_t)stream))) != MARL_OK) return rc;
         MARL_DISPATCH_NPAD(p->N, env_step_front_kernel, dim3(s->E), wave_lds_bytes(p->N), stream, *p, *s, *io);
+        if (after != nullptr && (rc = hip_check(hipEventRecord(after, (hipStream_t)stream))) != MARL_OK) return rc;
         return hip_check(hipGetLastError());
     }
     hipLaunchKernelGGL(env_step_front_kernel<0>, dim3(s->E), dim3(WAVE), front_lds_bytes(), (hipStream_t)stream, *p, *s, *io);
     hipLaunchKernelGGL(solve_order_kernel, dim3((s->E + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, (int)s->E, *s);
+    if (before != nullptr && (rc = hip_check(hipEventRecord(before, (hipStream_t)stream))) != MARL_OK) return rc;
     // one block more than envs: the last one never has a solve and clears the histogram
     const int all_cus = cu_count();
     const bool lanczos = p->N > 32 && (solver == MARL_LAMBDA2_LANCZOS ||
@@ -3465,7 +3473,18 @@ int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepI
     } else {
         MARL_DISPATCH_NPAD(p->N, env_step_solve_kernel, dim3(s->E + 1), 0, stream, *p, *s, *io);
     }
+    if (after != nullptr && (rc = hip_check(hipEventRecord(after, (hipStream_t)stream))) != MARL_OK) return rc;
     return hip_check(hipGetLastError());
+}
+
+int marl_env_step(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepIO* io, void* stream) {
+    return step_launches(p, s, io, stream, nullptr, nullptr);
+}
+
+int marl_env_step_timed(const MarlEnvParams* p, const MarlEnvState* s, const MarlStepIO* io, void* stream,
+                        void* solve_begin, void* solve_end) {
+    if (solve_begin == nullptr || solve_end == nullptr) return MARL_EINVAL;
+    return step_launches(p, s, io, stream, (hipEvent_t)solve_begin, (hipEvent_t)solve_end);
 }
 
 int marl_env_reset(const MarlEnvParams* p, const MarlEnvState* s, const MarlResetIO* io, void* stream) {

@@ -287,14 +287,17 @@ class BatchedJammerEnv:
     def step(self, actions: torch.Tensor, noise: Optional[torch.Tensor] = None, *,
              out_obs: Optional[torch.Tensor] = None, out_reward: Optional[torch.Tensor] = None,
              out_truncated: Optional[torch.Tensor] = None, episode_stats: Optional[torch.Tensor] = None,
-             episode_info: bool = True):
+             episode_info: bool = True, solve_events: Optional[Tuple[torch.cuda.Event, torch.cuda.Event]] = None,
+             out_reward_terms: Optional[torch.Tensor] = None, out_avg_power: Optional[torch.Tensor] = None):
         """One JammerEnv.step per env.  `actions` [E,M,3] float32 on the device.
         `noise` [E,N,2] float64 replaces the on-device enemy noise generator.
         out_* let the caller have results written straight into its own storage
-        (e.g. slot t of a rollout buffer).  `episode_stats` [4] float64: every episode that ends with this
+        (e.g. slot t of a rollout buffer; `out_reward_terms` [E,5] float32 and `out_avg_power` [E] float64, the
+        info-only mean jamming power of jammer_env.py:510-560, likewise).  `episode_stats` [4] float64: every episode that ends with this
         step adds 1, its return, its lambda2 reduction (%) and its length (training/trainer.py:248-268).
         `episode_info=False` leaves the pre-reset copies `episode_lambda2_initial` / `episode_step` out of
-        `info` (two device copies per auto-reset)."""
+        `info` (two device copies per auto-reset).  `solve_events`: two timing events that the library records
+        around the launch holding the eigen-solves (measurement; one launch sequence only, not with parts)."""
         if actions.dtype != torch.float32 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         if tuple(actions.shape) != (self.E, self.M, 3):
@@ -312,13 +315,22 @@ class BatchedJammerEnv:
                 raise ValueError("episode_stats must be a float64 device tensor of 4 elements")
             stats = episode_stats.data_ptr()
         with_obs = self.write_obs or out_obs is not None
+        if solve_events is not None and self._shards:
+            raise ValueError("solve_events time one launch sequence: not available with num_shards > 1")
 
         io = MarlStepIO()
         io.actions, io.noise = actions.data_ptr(), _ptr(noise)
         io.obs = obs.data_ptr() if with_obs else None
         io.reward, io.truncated = reward.data_ptr(), trunc.data_ptr()
-        io.lambda2, io.reward_terms = self.lambda2.data_ptr(), self.reward_terms.data_ptr()
-        io.avg_power_dbm = _ptr(self.avg_power)
+        terms = self.reward_terms if out_reward_terms is None else out_reward_terms
+        avg_power = self.avg_power if out_avg_power is None else out_avg_power
+        if terms.dtype != torch.float32 or terms.numel() != self.E * 5 or not terms.is_contiguous():
+            raise ValueError(f"out_reward_terms must be contiguous float32 [{self.E},5]")
+        if avg_power is not None and (avg_power.dtype != torch.float64 or avg_power.numel() != self.E
+                                      or not avg_power.is_contiguous()):
+            raise ValueError(f"out_avg_power must be contiguous float64 [{self.E}]")
+        io.lambda2, io.reward_terms = self.lambda2.data_ptr(), terms.data_ptr()
+        io.avg_power_dbm = _ptr(avg_power)
         io.adj_bits, io.jam_bits = _ptr(self.adj_bits), _ptr(self.jam_bits)
         io.episode_stats = stats
         io.seed, io.env_offset = self.seed, self.env_offset
@@ -327,15 +339,21 @@ class BatchedJammerEnv:
                 _lib.check(self.lib.marl_env_step_parts(C.byref(self.params), C.byref(self.state), C.byref(io),
                                                         len(self._shards), self._part_streams, self._part_scratch),
                            "marl_env_step_parts")
+            elif solve_events is not None:
+                for ev in solve_events:
+                    ev.record()               # torch creates the HIP event on its first record
+                _lib.check(self.lib.marl_env_step_timed(C.byref(self.params), C.byref(self.state), C.byref(io), _stream(),
+                                                        C.c_void_p(solve_events[0].cuda_event),
+                                                        C.c_void_p(solve_events[1].cuda_event)), "marl_env_step_timed")
             else:
                 _lib.check(self.lib.marl_env_step(C.byref(self.params), C.byref(self.state), C.byref(io), _stream()),
                            "marl_env_step")
         v = self.views
         info: Dict[str, Any] = dict(lambda2_current=self.lambda2, lambda2_initial=v["lambda2_initial"],
                                     enemy_band=v["enemy_band"], n_clusters=v["n_clusters"],
-                                    step=v["step_count"], reward_terms=self.reward_terms)
-        if self.avg_power is not None:
-            info["avg_jamming_power_dbm"] = self.avg_power
+                                    step=v["step_count"], reward_terms=terms)
+        if avg_power is not None:
+            info["avg_jamming_power_dbm"] = avg_power
         truncated = trunc.view(torch.bool) if trunc.dtype == torch.uint8 else trunc
         if self._track_counts and torch.cuda.is_current_stream_capturing():
             self._track_counts, self._count_bounds = False, None

@@ -40,11 +40,32 @@ class RolloutLog:
         self.output_dir.mkdir(parents=True, exist_ok=True)
         self.history = {k: [] for k in HISTORY_KEYS}
         self.start_time = time.time()
-        self._csv_file = open(self.output_dir / "training_log.csv", "w", newline="")
+        self._csv_file = None
+        self._csv = None
+        self._append = False
+
+    def resume(self):
+        """A run that continues from a checkpoint keeps the rows it has: history.json is read back if present and
+        training_log.csv is appended to instead of started over."""
+        hp = self.output_dir / "history.json"
+        if hp.exists():
+            with open(hp) as f:
+                old = json.load(f)
+            self.history = {k: list(old.get(k, [])) for k in HISTORY_KEYS}
+            if self.history["time_elapsed"]:
+                self.start_time = time.time() - float(self.history["time_elapsed"][-1])
+        self._append = (self.output_dir / "training_log.csv").exists()
+
+    def _open(self):
+        path = self.output_dir / "training_log.csv"
+        self._csv_file = open(path, "a" if self._append else "w", newline="")
         self._csv = csv.DictWriter(self._csv_file, fieldnames=list(HISTORY_KEYS))
-        self._csv.writeheader()
+        if not self._append:
+            self._csv.writeheader()
 
     def log_rollout(self, **rec):
+        if self._csv_file is None:
+            self._open()
         rec = {k: rec.get(k, 0.0) for k in HISTORY_KEYS}
         rec["time_elapsed"] = time.time() - self.start_time
         for k, v in rec.items():
@@ -63,6 +84,7 @@ class RolloutLog:
         if self._csv_file:
             self._csv_file.close()
             self._csv_file = None
+            self._append = True
 
 
 class BatchedTrainer:
@@ -71,7 +93,7 @@ class BatchedTrainer:
                  minibatches_per_epoch: int = 32, use_graph: bool = True, output_dir: Optional[str] = None,
                  log_interval: int = 1, save_interval: int = 10, eval_interval: int = 10, eval_episodes: int = 5,
                  target_reduction: float = 70.0, convergence_window: int = 50, early_stop_patience: int = 100,
-                 disable_early_convergence: bool = False):
+                 disable_early_convergence: bool = False, log_step_info: bool = True):
         rank = torch.distributed.get_rank() if _dist_on() else 0
         self.rank = rank
         self.world = torch.distributed.get_world_size() if _dist_on() else 1
@@ -81,6 +103,16 @@ class BatchedTrainer:
         self.total_budget = total_timesteps
         self.env = BatchedJammerEnv(num_envs, env_cfg, seed=seed, device=self.device, auto_reset=True,
                                     env_offset=rank * num_envs)
+        # What the reference's rollout loop reads from `info` at every step (training/trainer.py:239-245): the mean
+        # jamming power at the link midpoints and the band matches.  One slot per step of the rollout, written by the
+        # step kernel, reduced once per rollout.  (The reference's env never puts `band_match_rate` into `info`
+        # (jammer_env.py:443-455), so its column is always 0.0; here it is the mean of the reward's band-match
+        # term, the fraction of jammers on the enemy's band.)
+        self.log_step_info = bool(log_step_info)
+        self._power = torch.zeros(rollout_length, num_envs, dtype=torch.float64, device=self.device) \
+            if self.log_step_info else None
+        self._terms = torch.zeros(rollout_length, num_envs, 5, dtype=torch.float32, device=self.device) \
+            if self.log_step_info else None
         # The reference's defaults (2048-step rollout of one env, M = 4, minibatches of 256:
         # training/config.py:86-96) give 32 optimiser steps per epoch; a batched rollout holds E*T*M
         # samples, so the minibatch grows with it and the number of steps per epoch stays the same.
@@ -119,10 +151,12 @@ class BatchedTrainer:
         self._stats.zero_()
         obs = self._obs
         tick = env.views["tick"]
-        for _ in range(self.T):
+        for t in range(self.T):
             actions, rew_out, done_out, obs_out = agent.act_into_buffer(obs, tick=tick, env_offset=env.env_offset)
             obs, _, _, truncated, _ = env.step(actions, out_obs=obs_out, out_reward=rew_out, out_truncated=done_out,
-                                               episode_stats=self._stats, episode_info=False)
+                                               episode_stats=self._stats, episode_info=False,
+                                               out_reward_terms=self._terms[t] if self.log_step_info else None,
+                                               out_avg_power=self._power[t] if self.log_step_info else None)
             agent.commit_step()
         self._obs.copy_(obs)
         self._done.copy_(truncated)
@@ -155,16 +189,25 @@ class BatchedTrainer:
             self._graph.replay()
             agent.buffer.pos, agent.buffer.full = self.T, True
             agent.total_timesteps += self.T * self.E
-        stats = self._stats.clone()
+        if self.log_step_info:
+            per_step = torch.stack([self._power.sum(), self._terms[..., 1].sum(dtype=torch.float64)])
+        else:
+            per_step = torch.zeros(2, dtype=torch.float64, device=self.device)
+        stats = torch.cat([self._stats, per_step])
         if _dist_on():
             torch.distributed.all_reduce(stats)
         stats = stats.cpu()
         self.total_timesteps += self.T * self.E * self.world
         n = max(float(stats[0]), 1.0)
+        samples = float(self.T * self.E * self.world)
         self.total_episodes += int(stats[0])
         return {"steps": self.T * self.E * self.world, "episodes_completed": int(stats[0]),
                 "mean_reward": float(stats[1]) / n, "mean_lambda2_reduction": float(stats[2]) / n,
-                "mean_length": float(stats[3]) / n}
+                "mean_length": float(stats[3]) / n,
+                # mean over the steps of the rollout (training/trainer.py:293); -80.0 is what the reference reports
+                # when it has no value
+                "mean_jamming_power_dbm": float(stats[4]) / samples if self.log_step_info else -80.0,
+                "band_match_rate": float(stats[5]) / samples}
 
     def update(self) -> Dict[str, float]:
         return self.agent.update(self._obs, self._done)
@@ -182,6 +225,7 @@ class BatchedTrainer:
         act = torch.empty(num_envs, cfg.M, 3, device=self.device)
         logp = torch.empty(num_envs, cfg.M, device=self.device)
         rets, reds, frag = [], [], []
+        band = torch.zeros((), dtype=torch.float64, device=self.device)
         for ep in range(n_episodes):
             obs, info = env.reset()
             lam0 = info["lambda2_initial"].clone()
@@ -197,13 +241,14 @@ class BatchedTrainer:
                 obs, reward, _, truncated, info = env.step(a)
                 ret += reward.double()
                 fragmented |= info["lambda2_current"] < 1e-10
+                band += info["reward_terms"][:, 1].sum(dtype=torch.float64)
             lam = info["lambda2_current"]
             red = torch.where(lam0 > 1e-10, 100.0 * (1.0 - lam / lam0), torch.zeros_like(lam0))
             rets.append(ret); reds.append(red); frag.append(fragmented.double())
         agent.set_training_mode(True)
         rets, reds, frag = (torch.cat(x) for x in (rets, reds, frag))
         moments = torch.stack([torch.tensor(float(rets.numel()), dtype=torch.float64, device=self.device), rets.sum(),
-                               (rets ** 2).sum(), reds.sum(), (reds ** 2).sum(), frag.sum()])
+                               (rets ** 2).sum(), reds.sum(), (reds ** 2).sum(), frag.sum(), band])
         if _dist_on():
             torch.distributed.all_reduce(moments)
         m = moments.cpu().numpy()
@@ -211,7 +256,7 @@ class BatchedTrainer:
         std = lambda s, q: float(np.sqrt(max(q / n - (s / n) ** 2, 0.0)))
         return {"reward_mean": float(m[1] / n), "reward_std": std(m[1], m[2]),
                 "lambda2_reduction_mean": float(m[3] / n), "lambda2_reduction_std": std(m[3], m[4]),
-                "episode_length_mean": float(cfg.max_steps), "band_match_rate_mean": 0.0,
+                "episode_length_mean": float(cfg.max_steps), "band_match_rate_mean": float(m[6] / (n * cfg.max_steps)),
                 "fragmentation_rate": float(m[5] / n), "episodes": int(n)}
 
     # -- checkpoints (training/trainer.py:387-420) ----------------------------------
@@ -229,7 +274,10 @@ class BatchedTrainer:
                 json.dump({"total_timesteps": self.total_timesteps, "total_episodes": self.total_episodes,
                            "total_rollouts": self.total_rollouts, "best_reduction": self.best_reduction,
                            "no_improvement_count": self.no_improvement_count, "num_envs": self.E,
-                           "rollout_length": self.T, "world_size": self.world}, f, indent=2)
+                           "rollout_length": self.T, "world_size": self.world,
+                           "recent_reductions": [float(x) for x in self._reductions]}, f, indent=2)
+            if self.logger is not None:
+                self.logger.save()                 # history.json beside the CSV, so that a resumed run appends to both
         torch.cuda.synchronize(self.device)
         env = self.env
         bounds = env._count_bounds
@@ -257,6 +305,10 @@ class BatchedTrainer:
             self.total_rollouts = st.get("total_rollouts", 0)
             self.best_reduction = st.get("best_reduction", 0.0)
             self.no_improvement_count = st.get("no_improvement_count", 0)
+            self._reductions.clear()
+            self._reductions.extend(st.get("recent_reductions", []))
+        if self.logger is not None:
+            self.logger.resume()
         ep = base / f"env_state_{self.rank}.pt"
         if ep.exists():
             ck = torch.load(ep, map_location="cpu", weights_only=True)
@@ -309,8 +361,8 @@ class BatchedTrainer:
             if self.logger is not None:
                 self.logger.log_rollout(timestep=self.total_timesteps, episode=self.total_episodes,
                                         reward=roll["mean_reward"], lambda2_reduction=roll["mean_lambda2_reduction"],
-                                        episode_length=roll["mean_length"], band_match_rate=0.0,
-                                        avg_jamming_power_dbm=-80.0, **upd)
+                                        episode_length=roll["mean_length"], band_match_rate=roll["band_match_rate"],
+                                        avg_jamming_power_dbm=roll["mean_jamming_power_dbm"], **upd)
             if log is not None and self.rank == 0 and self.total_rollouts % max(self.log_interval, 1) == 0:
                 log(f"[Rollout {self.total_rollouts}] Steps: {self.total_timesteps:,} | Episodes: {self.total_episodes} | "
                     f"Reward: {roll['mean_reward']:.2f} | L2_red: {roll['mean_lambda2_reduction']:.1f}% | "

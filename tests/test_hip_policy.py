@@ -168,6 +168,14 @@ def test_trainer_logs_checkpoints_evaluates_and_resumes(tmp_path):
     assert rows[0].split(",") == list(HISTORY_KEYS) and len(rows) == 3
     hist = json.load(open(out / "history.json"))
     assert set(hist) == set(HISTORY_KEYS) and hist["timestep"] == [1280, 2560]
+    # per-step info of the rollout loop (training/trainer.py:239-245, 293): real values, not the defaults
+    assert all(-80.0 < x < 0.0 for x in hist["avg_jamming_power_dbm"]) and all(0.0 <= x <= 1.0 for x in hist["band_match_rate"])
+    terms, power, buf = a._terms, a._power, a.agent.buffer
+    assert abs(hist["avg_jamming_power_dbm"][-1] - float(power.mean())) < 1e-9
+    assert abs(hist["band_match_rate"][-1] - float(terms[..., 1].double().mean())) < 1e-9
+    # the band-match term of step t is the mean of feature 4 of the observation it produced, unless the env started over
+    keep = ~buf.dones_u8.bool()
+    assert torch.allclose(terms[:, :, 1][keep], buf.observations[1:, :, :, 4].mean(-1)[keep], atol=1e-6) and bool(keep.any())
     assert set(json.load(open(out / "final_stats.json"))) >= {"total_timesteps", "total_episodes", "total_rollouts",
                                                                  "best_lambda2_reduction", "time_elapsed", "fps"}
     for name in ("rollout_1", "rollout_2", "latest", "final"):
@@ -176,6 +184,7 @@ def test_trainer_logs_checkpoints_evaluates_and_resumes(tmp_path):
         assert (d / "env_state_0.pt").exists()
     st = json.load(open(out / "checkpoints" / "rollout_1" / "trainer_state.json"))
     assert st["total_rollouts"] == 1 and st["total_timesteps"] == 1280 and "best_reduction" in st
+    assert st["recent_reductions"] == list(a._reductions)[:1]
     ev = a.evaluate(n_episodes=2, num_envs=32)
     assert ev["episodes"] == 64 and ev["episode_length_mean"] == 15 and 0.0 <= ev["fragmentation_rate"] <= 1.0
     assert np.isfinite(ev["reward_mean"]) and ev["lambda2_reduction_std"] >= 0.0
@@ -195,6 +204,16 @@ def test_trainer_logs_checkpoints_evaluates_and_resumes(tmp_path):
     for p, q in zip(list(b.agent.actor.parameters()) + list(b.agent.critic.parameters()),
                     list(c.agent.actor.parameters()) + list(c.agent.critic.parameters())):
         assert torch.equal(p, q)
+    # a run that resumes in the same output directory keeps its log: rows are appended, the window of the
+    # convergence test comes back
+    e = mk(str(out))
+    e.load_checkpoint(str(out / "checkpoints" / "latest"))
+    assert list(e._reductions) == list(a._reductions) and e.total_rollouts == 2
+    e.train(max_rollouts=3, log=None)
+    rows = open(out / "training_log.csv").read().strip().splitlines()
+    assert rows[0].split(",") == list(HISTORY_KEYS) and len(rows) == 4
+    assert [int(float(r.split(",")[0])) for r in rows[1:]] == [1280, 2560, 3840]
+    assert json.load(open(out / "history.json"))["timestep"] == [1280, 2560, 3840]
     # and the convergence test (training/trainer.py:422-458)
     t = mk(str(tmp_path / "d"))
     t.convergence_window, t.target_reduction = 3, 50.0
@@ -221,6 +240,8 @@ def test_rollout_graph_replay_matches_eager_rollout():
             assert b._graph is not None
         assert ra["episodes_completed"] == rb["episodes_completed"] > 0
         assert abs(ra["mean_reward"] - rb["mean_reward"]) < 1e-9 and abs(ra["mean_lambda2_reduction"] - rb["mean_lambda2_reduction"]) < 1e-9
+        assert ra["mean_jamming_power_dbm"] == rb["mean_jamming_power_dbm"] and ra["band_match_rate"] == rb["band_match_rate"]
+        assert -80.0 < ra["mean_jamming_power_dbm"] < 0.0
         for name in ("observations", "actions", "log_probs", "rewards", "dones_u8", "values"):
             assert torch.equal(getattr(a.agent.buffer, name), getattr(b.agent.buffer, name)), (r, name)
         assert torch.equal(a.env.views["enemy_x"], b.env.views["enemy_x"])

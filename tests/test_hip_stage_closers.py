@@ -119,6 +119,32 @@ def test_step_and_reward_only_schedules_agree_bit_for_bit():
             assert all(torch.equal(a, b) for a, b in zip(outs[0], o)), t
 
 
+@pytest.mark.parametrize("N,M,E", [(50, 8, 2048), (10, 4, 512), (100, 8, 64)])
+def test_timed_step_equals_the_step_and_times_the_solve_launch(N, M, E):
+    """marl_env_step_timed issues the launches of marl_env_step (three-launch, one-launch and wide-team schedules)
+    and its two events bracket one of them: same results bit for bit, a positive time below the step's own."""
+    envs = [BatchedJammerEnv(E, EnvConfig.fast_preset(N=N, M=M), seed=3, auto_reset=True) for _ in range(2)]
+    for env in envs:
+        env.reset()
+    g = torch.Generator(device="cuda").manual_seed(17)
+    for t in range(12):
+        act = (torch.rand(E, M, 3, device="cuda", generator=g) - 0.5) * 10
+        act[..., 2] = torch.randint(0, 4, (E, M), device="cuda", generator=g).float()
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        whole = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        o0, r0, _, _, i0 = envs[0].step(act)
+        whole[0].record()
+        o1, r1, _, _, i1 = envs[1].step(act, solve_events=ev)
+        whole[1].record()
+        torch.cuda.synchronize()
+        assert torch.equal(o0, o1) and torch.equal(r0, r1), t
+        assert torch.equal(i0["lambda2_current"], i1["lambda2_current"]), t
+        assert 0.0 < ev[0].elapsed_time(ev[1]) <= whole[0].elapsed_time(whole[1]), t
+    with pytest.raises(ValueError):
+        BatchedJammerEnv(64, EnvConfig.fast_preset(N=10, M=4), seed=1, num_shards=2).step(
+            torch.zeros(64, 4, 3, device="cuda"), solve_events=ev)
+
+
 # ---------------------------------------------------------------- reward + observation stage
 def _stage_groups():
     groups = {}

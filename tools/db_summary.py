@@ -39,7 +39,8 @@ def stats(out, dbp):
 
 
 STEP_KERNELS = ("env_step_front_kernel", "solve_order_kernel", "env_step_solve_kernel", "env_step_solve_prio_kernel",
-                "env_step_big_kernel", "env_step_team_kernel")
+                "env_step_solve_lanczos_kernel", "env_step_big_kernel", "env_step_team_kernel")
+SOLVE_KERNELS = ("env_step_solve_kernel", "env_step_solve_prio_kernel", "env_step_solve_lanczos_kernel", "env_step_team_kernel")
 
 
 def pmc(out, dbs):
@@ -56,8 +57,9 @@ def pmc(out, dbs):
                 continue
             per[cname][k] += val
             disp[k].add(did)
-        steps = max((len(v) for k, v in disp.items() if k.startswith(("env_step_solve_kernel", "env_step_solve_prio_kernel", "env_step_big_kernel"))),
-                    default=0)
+        # one step = one launch of the kernel that holds the solves (the front kernel itself in the one-launch schedule)
+        steps = max((len(v) for k, v in disp.items() if k.startswith(SOLVE_KERNELS)), default=0) or \
+            max((len(v) for k, v in disp.items() if k.startswith("env_step_front_kernel")), default=1)
         for cname, byk in per.items():
             res["per_step"][cname] = sum(byk.values()) / steps
             res["per_kernel_launch"][cname] = {k: v / len(disp[k]) for k, v in byk.items()}
@@ -71,12 +73,14 @@ def summary(out, stats_csv, pmc_json=None):
     of the eigen-solve launch, and from the counter passes HBM bytes per step (FETCH_SIZE doubled as prescribed
     for gfx950, + WRITE_SIZE; both are reported in KiB) and VALU busy per kernel
     (SQ_ACTIVE_INST_VALU x 4 / (SQ_BUSY_CYCLES x 32): quad-cycles over the busy cycles of 32 SIMDs per counter instance)."""
-    res = {"kernel_avg_us": {}}
+    import os
+    res = {"git_head": os.environ.get("PROFILE_GIT_HEAD", "unknown"), "command": os.environ.get("PROFILE_COMMAND", ""),
+           "kernel_avg_us": {}}
     for row in csv.DictReader(open(stats_csv)):
         if row["AverageNs"]:
             res["kernel_avg_us"][row["Name"]] = float(row["AverageNs"]) / 1e3
     for k, v in res["kernel_avg_us"].items():
-        if k.startswith(("env_step_solve_kernel", "env_step_solve_prio_kernel", "env_step_team_kernel")):
+        if k.startswith(SOLVE_KERNELS):
             res["solve_kernel_us"] = v
     if pmc_json:
         p = json.load(open(pmc_json))
