@@ -68,6 +68,9 @@ extern "C" {
                                            batches that the chip holds in about one round of solve waves, a solve's issue
                                            priority follows the work it has left, so that the solves of a SIMD finish together);
                                            marl_env_step_parts sets it for its parts */
+#define MARL_STAGE_GENERAL_RESET 4        /* marl_env_reset takes its general kernel even where the un-jammed graph is known to be
+                                           complete (generated spawns in an arena whose diagonal every band's communication
+                                           range exceeds: lambda2_initial = N without adjacency test or eigen-solve); testing */
 
 enum {
     MARL_OK = 0,

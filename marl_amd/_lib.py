@@ -19,6 +19,7 @@ ENEMY_RANDOM_WALK, ENEMY_COORDINATED_TURN = 0, 1
 SCHEDULE_AUTO, SCHEDULE_FUSED, SCHEDULE_SPLIT = 0, 1, 2
 STAGE_NO_RECLUSTER = 1
 STAGE_NO_SOLVE_PRIORITY = 2
+STAGE_GENERAL_RESET = 4
 LAMBDA2_DIRECT, LAMBDA2_LANCZOS = 0x100, 0x200
 
 MARL_OK, MARL_EINVAL, MARL_EUNSUPPORTED, MARL_EHIP, MARL_ETOOBIG = 0, -1, -2, -3, -4

@@ -1541,7 +1541,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 
 
 // Order: env indices of the pending solves into solve_perm, largest matrix first (a counting sort
 // over the histogram the front kernel built).  Every block derives the bin offsets itself.
-__global__ __launch_bounds__(1024) void solve_order_kernel(int E, MarlEnvState S) {
+// prio_slots: wave slots of the chip for the solve kernel (0: the launch does not schedule by priority).  A launch of
+// between SOLVE_PRIO_ITEMS_MIN and SOLVE_PRIO_ITEMS_MAX percent of them -- about one round of waves -- runs with every
+// solve's issue priority following the work it has left (SolvePriority); the verdict goes to the solve blocks through
+// solve_hist[SOLVE_HIST_TOTAL + 2] (1 or 0).
+enum { SOLVE_PRIO_ITEMS_MIN = 99, SOLVE_PRIO_ITEMS_MAX = 130 };
+__global__ __launch_bounds__(1024) void solve_order_kernel(int E, MarlEnvState S, int prio_slots) {
     __shared__ int start[SOLVE_HIST_SUBS][WAVE + 1];
     if (threadIdx.x < WAVE) {                        // lane i stands for bin 64 - i: largest matrices first
         const int bin = WAVE - (int)threadIdx.x;
@@ -1566,6 +1571,11 @@ __global__ __launch_bounds__(1024) void solve_order_kernel(int E, MarlEnvState S
         }
         if (blockIdx.x == 0 && threadIdx.x == WAVE - 1) S.solve_hist[SOLVE_HIST_TOTAL] = incl;
         if (blockIdx.x == 0 && threadIdx.x == WAVE / 2 - 1) S.solve_hist[SOLVE_HIST_TOTAL + 1] = incl;     // problems of more than 32 vertices
+        const int total = __shfl(incl, WAVE - 1), nbig = __shfl(incl, WAVE / 2 - 1);
+        const int nitems = nbig + ((total - nbig + 1) >> 1);
+        const bool by_priority = prio_slots > 0 && nitems * 100 >= SOLVE_PRIO_ITEMS_MIN * prio_slots &&
+                                 nitems * 100 <= SOLVE_PRIO_ITEMS_MAX * prio_slots;
+        if (blockIdx.x == 0 && threadIdx.x == 0) S.solve_hist[SOLVE_HIST_TOTAL + 2] = by_priority ? 1 : 0;
     }
     __syncthreads();
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1662,16 +1672,20 @@ __device__ __forceinline__ void solve_block(const MarlEnvParams& P, const MarlEn
             for (int k = lane; k < SOLVE_HIST_TOTAL; k += WAVE) S.solve_hist[k] = 0;
         return;
     }
-    solve_item<NPAD, PRIO, LANCZOS>(P, S, io, (int)blockIdx.x, nbig, total, lane, L);
+    if constexpr (PRIO) {
+        // Whether this launch schedules by priority was decided by the order kernel, from the number of its items.  Two
+        // copies of the solver, one taken by every block of a launch: keeping the books of the priority costs a solve
+        // 2-3 % even when no level is ever changed.
+        if (S.solve_hist[SOLVE_HIST_TOTAL + 2]) solve_item<NPAD, true, LANCZOS>(P, S, io, (int)blockIdx.x, nbig, total, lane, L);
+        else solve_item<NPAD, false, LANCZOS>(P, S, io, (int)blockIdx.x, nbig, total, lane, L);
+    } else {
+        solve_item<NPAD, false, LANCZOS>(P, S, io, (int)blockIdx.x, nbig, total, lane, L);
+    }
 }
+// In launches that the chip holds in about one round of waves (the order kernel's verdict) the issue priority of every
+// solve follows the work it has left (SolvePriority), so that the solves of a SIMD finish together.
 template <int NPAD>
 __global__ __launch_bounds__(WAVE) void env_step_solve_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
-    solve_block<NPAD, false>(P, S, io);
-}
-// The same with the issue priority of every solve following the work it has left (SolvePriority): for launches that
-// the chip holds in one round, where the solves of a SIMD should finish together.
-template <int NPAD>
-__global__ __launch_bounds__(WAVE) void env_step_solve_prio_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
     solve_block<NPAD, true>(P, S, io);
 }
 // The same with the problems of more than 32 vertices going through the Lanczos iteration first (lanczos_solve.inc).
@@ -1684,8 +1698,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 8))) vo
 }
 
 // ------------------------------------------------------------------ reset kernel (N <= 64)
-template <int NPAD>
-__global__ __launch_bounds__(WAVE) void env_reset_wave_kernel(MarlEnvParams P, MarlEnvState S, MarlResetIO io) {
+// COMPLETE: the caller knows that the un-jammed graph is the complete one whatever is drawn (generated spawns lie in
+// [0.1 A, 0.9 A]^2 and every band's communication range exceeds the arena's diagonal): lambda2 = N without adjacency
+// test and without the eigensolver's registers, so that six to eight envs share a SIMD instead of one.
+template <int NPAD, bool COMPLETE = false>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(COMPLETE ? 4 : 1, 8)))
+void env_reset_wave_kernel(MarlEnvParams P, MarlEnvState S, MarlResetIO io) {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds& L = carve(smem);
     const int e = blockIdx.x, lane = threadIdx.x;
@@ -1740,8 +1758,12 @@ __global__ __launch_bounds__(WAVE) void env_reset_wave_kernel(MarlEnvParams P, M
         }
         WSYNC();
         // lambda2 of the un-jammed graph (jammer_env.py:301)
-        const uint64_t adj = adjacency_row(L, n, lane, P.comm_d2_max[eband]);
-        lam0 = lambda2_wave<NPAD>(adj, n, lane, L, P.lambda2_rounds);
+        if constexpr (COMPLETE) {
+            lam0 = n <= 1 ? 0.0 : (double)n;
+        } else {
+            const uint64_t adj = adjacency_row(L, n, lane, P.comm_d2_max[eband]);
+            lam0 = lambda2_wave<NPAD>(adj, n, lane, L, P.lambda2_rounds);
+        }
         if (lam0 >= P.min_lambda2_initial) break;
     }
     // jammers (jammer_env.py:321-339)
@@ -3256,7 +3278,7 @@ enum { LANCZOS_AUTO_ENVS_PER_CU = 48 };
 // room for the next ones and holding them back costs.  On 256 CUs, one launch sequence, us per step with / without:
 // 4 096 envs 76.9 / 74.6, 6 144 envs 88.6 / 88.0, 7 168 envs 100.5 / 103.7, 8 192 envs 106.2 / 111.3, 9 216 envs
 // 118.9 / 117.8, 10 240 envs 133.0 / 127.5 (tools/prio_sweep.sh).
-enum { SOLVE_PRIORITY_ENVS_PER_CU_MIN = 26, SOLVE_PRIORITY_ENVS_PER_CU_MAX = 34 };
+enum { SOLVE_WAVES_PER_CU = 16 };          // the direct solve kernel: four waves on each of a compute unit's four SIMDs
 
 // Compute units of the current device (cached per device; 0 on error).
 int cu_count() {
@@ -3329,7 +3351,7 @@ int marl_params_init(MarlEnvParams* p) {
     p->dt_f32 = (float)p->dt;
     p->v_max_f32 = (float)p->v_max;
     p->v_max_sq_f32 = (float)(p->v_max * p->v_max);
-    if (p->stage_flags & ~(MARL_STAGE_NO_RECLUSTER | MARL_STAGE_NO_SOLVE_PRIORITY)) return MARL_EINVAL;
+    if (p->stage_flags & ~(MARL_STAGE_NO_RECLUSTER | MARL_STAGE_NO_SOLVE_PRIORITY | MARL_STAGE_GENERAL_RESET)) return MARL_EINVAL;
     if (check_rounds(&p->lambda2_rounds) != MARL_OK) return MARL_EINVAL;
     return MARL_OK;
 }
@@ -3459,17 +3481,16 @@ static int step_launches(const MarlEnvParams* p, const MarlEnvState* s, const Ma
         return hip_check(hipGetLastError());
     }
     hipLaunchKernelGGL(env_step_front_kernel<0>, dim3(s->E), dim3(WAVE), front_lds_bytes(), (hipStream_t)stream, *p, *s, *io);
-    hipLaunchKernelGGL(solve_order_kernel, dim3((s->E + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, (int)s->E, *s);
-    if (before != nullptr && (rc = hip_check(hipEventRecord(before, (hipStream_t)stream))) != MARL_OK) return rc;
-    // one block more than envs: the last one never has a solve and clears the histogram
     const int all_cus = cu_count();
     const bool lanczos = p->N > 32 && (solver == MARL_LAMBDA2_LANCZOS ||
                                        (solver == 0 && all_cus > 0 && s->E >= LANCZOS_AUTO_ENVS_PER_CU * all_cus));
-    const int cus = (p->stage_flags & MARL_STAGE_NO_SOLVE_PRIORITY) ? 0 : all_cus;
+    const bool prio = !lanczos && all_cus > 0 && !(p->stage_flags & MARL_STAGE_NO_SOLVE_PRIORITY);
+    hipLaunchKernelGGL(solve_order_kernel, dim3((s->E + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, (int)s->E, *s,
+                       prio ? all_cus * SOLVE_WAVES_PER_CU : 0);
+    if (before != nullptr && (rc = hip_check(hipEventRecord(before, (hipStream_t)stream))) != MARL_OK) return rc;
+    // one block more than envs: the last one never has a solve and clears the histogram
     if (lanczos) {
         MARL_DISPATCH_NPAD_BIG(p->N, env_step_solve_lanczos_kernel, dim3(s->E + 1), 0, stream, *p, *s, *io);
-    } else if (cus > 0 && s->E >= SOLVE_PRIORITY_ENVS_PER_CU_MIN * cus && s->E <= SOLVE_PRIORITY_ENVS_PER_CU_MAX * cus) {
-        MARL_DISPATCH_NPAD(p->N, env_step_solve_prio_kernel, dim3(s->E + 1), 0, stream, *p, *s, *io);
     } else {
         MARL_DISPATCH_NPAD(p->N, env_step_solve_kernel, dim3(s->E + 1), 0, stream, *p, *s, *io);
     }
@@ -3499,6 +3520,12 @@ int marl_env_reset(const MarlEnvParams* p, const MarlEnvState* s, const MarlRese
     if (p->N > WAVE) {
         if (s->workspace == nullptr) return MARL_EINVAL;
         MARL_DISPATCH_SLOTS(p->N, env_reset_big_kernel, dim3(s->E), stream, *p, *s, *io);
+        return hip_check(hipGetLastError());
+    }
+    bool complete = io->enemy_pos == nullptr && p->arena_size > 0.0 && !(p->stage_flags & MARL_STAGE_GENERAL_RESET);
+    for (int b = 0; b < 4; ++b) complete = complete && p->comm_d2_max[b] >= 2.000001 * p->arena_size * p->arena_size;
+    if (complete) {
+        hipLaunchKernelGGL((env_reset_wave_kernel<0, true>), dim3(s->E), dim3(WAVE), front_lds_bytes(), (hipStream_t)stream, *p, *s, *io);
         return hip_check(hipGetLastError());
     }
     MARL_DISPATCH_NPAD(p->N, env_reset_wave_kernel, dim3(s->E), wave_lds_bytes(p->N), stream, *p, *s, *io);

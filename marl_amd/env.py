@@ -62,6 +62,7 @@ class EnvConfig:
     step_schedule: str = "auto"     # N <= 64: "auto", "fused" (one launch per step) or "split" (three, longest solve first)
     recluster: bool = True          # False: step() never re-clusters (the table of the last reset stays): "step + reward only"
     solve_priority: bool = True     # split schedule: the issue priority of an eigen-solve follows the work it has left
+    reset_shortcut: bool = True     # False (testing): the general reset kernel even where the un-jammed graph is known to be complete
     lambda2_solver: str = "auto"    # split schedule, N > 32: "direct" (Householder), "lanczos" (iteration first), or by the batch size
 
     @staticmethod
@@ -85,7 +86,8 @@ class EnvConfig:
         p.max_reset_attempts = int(self.max_reset_attempts)
         p.lambda2_rounds = int(self.lambda2_rounds) | {"auto": 0, "direct": _lib.LAMBDA2_DIRECT,
                                                        "lanczos": _lib.LAMBDA2_LANCZOS}[self.lambda2_solver]
-        p.stage_flags = (0 if self.recluster else _lib.STAGE_NO_RECLUSTER) | (0 if self.solve_priority else _lib.STAGE_NO_SOLVE_PRIORITY)
+        p.stage_flags = (0 if self.recluster else _lib.STAGE_NO_RECLUSTER) | (0 if self.solve_priority else _lib.STAGE_NO_SOLVE_PRIORITY) | \
+            (0 if self.reset_shortcut else _lib.STAGE_GENERAL_RESET)
         p.arena_size, p.dt, p.v_max, p.v_enemy = float(self.arena_size), float(self.dt), float(self.v_max), float(self.v_enemy)
         p.P_tx_w, p.P_sens_w = db_to_watts(self.P_tx_dbm), db_to_watts(self.P_sens_dbm)
         p.P_jam_w, p.P_thr_w = db_to_watts(self.P_jammer_dbm), db_to_watts(self.P_jam_thresh_dbm)

@@ -118,6 +118,35 @@ def test_device_reset_retry_loop_matches_oracle(random_start):
                 assert np.all(np.abs(jpos[j] - np.clip(st.clusters.cent_xy[slot], 0, p.arena_size)) <= 10.0 + 1e-9)
 
 
+@pytest.mark.parametrize("random_start,N,M", [(True, 50, 8), (False, 50, 8), (True, 64, 16), (False, 10, 4)])
+def test_reset_shortcut_for_always_complete_graphs_equals_general_reset(random_start, N, M):
+    """Where every generated spawn gives the complete graph (arena diagonal below every band's range) the reset
+    launch skips the adjacency test and the eigensolver; state, observations and everything downstream are those
+    of the general kernel bit for bit, over whole-batch resets, masked auto-resets and a reset of a chosen half."""
+    E = 384
+    mk = lambda shortcut: BatchedJammerEnv(E, EnvConfig.fast_preset(N=N, M=M, max_steps=13, reset_shortcut=shortcut,
+                                                                    random_jammer_start=random_start),
+                                           seed=21, auto_reset=True)
+    a, b = mk(True), mk(False)
+    oa, _ = a.reset()
+    ob, _ = b.reset()
+    assert torch.equal(oa, ob) and torch.all(a.views["lambda2_initial"] == float(N))
+    g = torch.Generator(device="cuda").manual_seed(9)
+    half = (torch.arange(E, device="cuda") % 2 == 0)
+    for t in range(30):
+        act = (torch.rand(E, M, 3, device="cuda", generator=g) - 0.5) * 10
+        act[..., 2] = torch.randint(0, 4, (E, M), device="cuda", generator=g).float()
+        ra, rb = a.step(act), b.step(act)
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(ra[3], rb[3]), t
+        if t == 20:
+            oa, _ = a.reset(mask=half)
+            ob, _ = b.reset(mask=half)
+            assert torch.equal(oa, ob)
+        for k in a.views:
+            if k not in ("solve_rows", "solve_np", "solve_slot", "solve_perm", "solve_partial"):
+                assert torch.equal(a.views[k], b.views[k]), (t, k)
+
+
 # ---------------------------------------------------------------- reference edge vectors through the step kernel
 def test_reflection_speed_floor_and_action_decode_vectors_through_the_step_kernel():
     """edges.npz refl_* (enemies leaving through every wall and a corner, zero velocity with zero noise ->
