@@ -1294,33 +1294,52 @@ __device__ __forceinline__ RewardOut reward_obs_wave(const MarlEnvParams& P, int
 
 // _compute_avg_jamming_power (jammer_env.py:510-560): mean over links i<j of the
 // strongest matching jammer's power at the link midpoint, in dBm; -80 when none.
-__device__ __forceinline__ double avg_power_wave(const MarlEnvParams& P, int n, int m, int lane, const WaveLds& L, int eband) {
-    int nm = 0;
-    for (int k = 0; k < m; ++k) nm += (L.jb[k] == eband);
-    if (nm == 0) return -80.0;
-    const double wl = kSpeedOfLight / band_hz(eband);
-    const double xi = L.sxy[lane & (WAVE - 1)].x, yi = L.sxy[lane & (WAVE - 1)].y;
-    double psum = 0.0;
+//
+// The strongest jammer is the nearest one, and P (wl / (4 pi d))^2 with d = max(sqrt(d2), 1e-10) is C / max(D2, 4e-20)
+// for D2 = |2 q - (p_i + p_j)|^2 = 4 d2 and C = 4 P (wl / 4 pi)^2: no square root, one reciprocal (45 bits) per link.
+// Enemy i takes the links to its (n - 1) / 2 successors on the circle 0..n-1 (even n: the first n / 2 also the one
+// opposite), so every link is evaluated once and all lanes stay busy.  The order of the sum is not numpy's: the
+// result agrees with the reference to about 1e-13 relative, not bit for bit (an info-only value).
+struct LinkPower {
+    double c4, psum = 0.0;
     int pcnt = 0;
-    for (int j = 0; j < n; ++j) {
-        double dmin = INFINITY;
-        const double mx = (xi + L.sxy[j].x) / 2, my = (yi + L.sxy[j].y) / 2;
-        for (int k = 0; k < m; ++k) {
-            if (L.jb[k] != eband) continue;
-            const double dx = L.jx[k] - mx, dy = L.jy[k] - my;
-            dmin = fmin(dmin, dx * dx + dy * dy);
-        }
-        if (lane < n && j > lane) {
-            const double d = fmax(sqrt(dmin), 1e-10);
-            const double g = wl / (kFourPi * d);
-            const double pw = P.P_jam_w * (g * g);
-            if (pw > 0.0) { psum += pw; ++pcnt; }
-        }
+    __device__ __forceinline__ LinkPower(const MarlEnvParams& P, int eband) {
+        const double g = kSpeedOfLight / band_hz(eband) / kFourPi;
+        c4 = 4.0 * P.P_jam_w * (g * g);
     }
-    const double tot = wave_sum(psum);
-    const int cnt = wave_sum(pcnt);
-    if (cnt == 0) return -80.0;
-    return 10.0 * log10(tot / (double)cnt) + 30.0;
+    // D2: four times the squared distance of the nearest matching jammer to the midpoint
+    __device__ __forceinline__ void add(double D2, bool counted) {
+        const double pw = c4 * rcp_45(fmax(D2, 4e-20));
+        if (counted && pw > 0.0) { psum += pw; ++pcnt; }
+    }
+    __device__ __forceinline__ double dbm() {
+        const double tot = wave_sum(psum);
+        const int cnt = wave_sum(pcnt);
+        if (cnt == 0) return -80.0;
+        return 10.0 * log10(tot / (double)cnt) + 30.0;
+    }
+};
+
+__device__ __forceinline__ double avg_power_wave(const MarlEnvParams& P, int n, int m, int lane, const WaveLds& L, int eband) {
+    const uint64_t matching = ballot64(lane < m && L.jb[lane & (WAVE - 1)] == eband);
+    if (matching == 0) return -80.0;
+    LinkPower acc(P, eband);
+    const double2 pi = L.sxy[lane & (WAVE - 1)];
+    const int half = (n - 1) >> 1, opposite = (n & 1) ? 0 : n >> 1;
+    for (int k = 1; k <= half + (opposite ? 1 : 0); ++k) {
+        int j = lane + k;
+        j = j >= n ? j - n : j;
+        const double2 pj = L.sxy[(lane < n) ? j : 0];
+        const double sx = pi.x + pj.x, sy = pi.y + pj.y;
+        double D2 = INFINITY;
+        for (uint64_t mk = matching; mk; mk &= mk - 1) {
+            const int q = __ffsll((unsigned long long)mk) - 1;
+            const double dx = fma(2.0, L.jx[q], -sx), dy = fma(2.0, L.jy[q], -sy);
+            D2 = fmin(D2, fma(dx, dx, dy * dy));
+        }
+        acc.add(D2, k <= half ? lane < n : lane < opposite);
+    }
+    return acc.dbm();
 }
 
 __device__ __forceinline__ void store_bits(uint32_t* dst, int e, int n, int lane, uint64_t row) {
@@ -2302,13 +2321,20 @@ __device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int 
             uint64_t cfull = ~rows[s][k] & word_mask<S>(n, k) & touched[k];
             if (k == s) cfull &= ~(1ull << lane);
             uint64_t t = touched[k];
-            while (t) {
-                const int v = __ffsll((unsigned long long)t) - 1;
-                const uint64_t bit = (cfull >> v) & 1ull;
+            while (t) {                         // one step per run of consecutive touched vertices (t, r: wave-uniform)
+                const int a = __ffsll((unsigned long long)t) - 1;
+                const uint64_t inv = ~(t >> a);                      // zero bits mark the end of the run
+                const int len = inv ? __ffsll((unsigned long long)inv) - 1 : 64;
+                const uint64_t ones = (len >= 64) ? ~0ull : ((1ull << len) - 1);
+                const uint64_t run = (cfull >> a) & ones;
+                const int qd = r >> 6, sh = r & 63;
 #pragma unroll
-                for (int q = 0; q < S; ++q) cw[q] |= (((r >> 6) == q) ? bit : 0ull) << (r & 63);
-                t &= t - 1;
-                ++r;
+                for (int q = 0; q < S; ++q) {
+                    if (q == qd) cw[q] |= run << sh;
+                    if (q == qd + 1 && sh != 0) cw[q] |= run >> (64 - sh);      // the part of the run that spills over
+                }
+                r += len;
+                t = (a + len >= 64) ? 0ull : (t & ~(ones << a));
             }
         }
         if ((touched[s] >> lane) & 1ull) {
@@ -2524,33 +2550,27 @@ __device__ __forceinline__ double avg_power_big(const MarlEnvParams& P, int n, i
     int nm = 0;
     for (int k = 0; k < m; ++k) nm += (L.jb[k] == eband);
     if (nm == 0) return -80.0;
-    const double wl = kSpeedOfLight / band_hz(eband);
-    double psum = 0.0;
-    int pcnt = 0;
+    LinkPower acc(P, eband);
+    const int half = (n - 1) >> 1, opposite = (n & 1) ? 0 : n >> 1;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int i = s * WAVE + lane;
-        const double xi = L.sx[i], yi = L.sy[i];
-        for (int j = 0; j < n; ++j) {
-            double dmin = INFINITY;
-            const double mx = (xi + L.sx[j]) / 2, my = (yi + L.sy[j]) / 2;
-            for (int k = 0; k < m; ++k) {
-                if (L.jb[k] != eband) continue;
-                const double dx = L.jx[k] - mx, dy = L.jy[k] - my;
-                dmin = fmin(dmin, dx * dx + dy * dy);
+        const double xi = L.sx[i < n ? i : 0], yi = L.sy[i < n ? i : 0];
+        for (int k = 1; k <= half + (opposite ? 1 : 0); ++k) {
+            int j = i + k;
+            j = j >= n ? j - n : j;
+            j = i < n ? j : 0;
+            const double sx = xi + L.sx[j], sy = yi + L.sy[j];
+            double D2 = INFINITY;
+            for (int q = 0; q < m; ++q) {
+                if (L.jb[q] != eband) continue;
+                const double dx = fma(2.0, L.jx[q], -sx), dy = fma(2.0, L.jy[q], -sy);
+                D2 = fmin(D2, fma(dx, dx, dy * dy));
             }
-            if (i < n && j > i) {
-                const double d = fmax(sqrt(dmin), 1e-10);
-                const double g = wl / (kFourPi * d);
-                const double pw = P.P_jam_w * (g * g);
-                if (pw > 0.0) { psum += pw; ++pcnt; }
-            }
+            acc.add(D2, k <= half ? i < n : i < opposite);
         }
     }
-    const double tot = wave_sum(psum);
-    const int cnt = wave_sum(pcnt);
-    if (cnt == 0) return -80.0;
-    return 10.0 * log10(tot / (double)cnt) + 30.0;
+    return acc.dbm();
 }
 
 template <int S>
@@ -3035,6 +3055,49 @@ __global__ __launch_bounds__(TEAM_THREADS) void env_step_team_kernel(MarlEnvPara
     }
 }
 
+// Between the two launches of a step for 64 < N <= 256 (and of the stage op): the Lanczos iteration on the pending
+// eigenproblems, one wave each, straight from the compacted bit rows.  A problem that meets its bound is finished here
+// (pending count cleared: the team kernel's workgroup for it leaves at once); the others stay for the direct solver.
+template <int S>
+__global__ __launch_bounds__(WAVE) void env_step_lanczos_rows_kernel(MarlEnvParams P, MarlEnvState St, MarlStepIO io) {
+    __shared__ LanczosRowsLds<S> L;
+    const int e = blockIdx.x, lane = threadIdx.x;
+    int* pend = workspace_pending(St.workspace, P.N, St.E);
+    const int np = pend[e];
+    if (np <= 0) return;
+    const size_t ld = (size_t)big_ld(P.N);
+    double mu;
+    if (!mu_max_lanczos_rows<S>(reinterpret_cast<const unsigned long long*>(St.workspace + (size_t)e * ld * ld), np, lane,
+                                (double)P.N, L, P.lambda2_rounds, mu))
+        return;
+    if (lane == 0) {
+        const double lam = (double)P.N - mu;
+        const double* part = St.solve_partial + (size_t)e * 4;
+        double r1;
+        const double lam0 = St.lambda2_initial[e];
+        const double total_r = reward_total(P, lam, lam0, part[0], part[1], (float)part[2], part[3], r1);
+        finish_env(P, St, io, e, St.step_count[e], total_r, lam, lam0);
+        if (io.reward_terms) io.reward_terms[(size_t)e * 5] = (float)r1;
+        pend[e] = 0;
+    }
+}
+template <int S>
+__global__ __launch_bounds__(WAVE) void lambda2_lanczos_rows_kernel(int n, int* pend, const double* ws, size_t ws_stride,
+                                                                    double* lambda2, int rounds) {
+    __shared__ LanczosRowsLds<S> L;
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int np = pend[e];
+    if (np <= 0) return;
+    double mu;
+    if (!mu_max_lanczos_rows<S>(reinterpret_cast<const unsigned long long*>(ws + (size_t)e * ws_stride), np, lane, (double)n, L,
+                                rounds, mu))
+        return;
+    if (lane == 0) {
+        lambda2[e] = (double)n - mu;
+        pend[e] = 0;
+    }
+}
+
 template <int S>
 __global__ __launch_bounds__(WAVE) void lambda2_bits_big_kernel(int n, const uint32_t* bits, double* lambda2, int rounds,
                                                                 double* ws, int* pend) {
@@ -3206,9 +3269,10 @@ size_t workspace_bytes(int N, int E) {
 
 
 // Team solver launch: 104 columns per thread beyond 128 vertices, 64 up to there.
-#ifdef MARL_DEV_FAST      /* development builds leave the kernels for N > 64 out */
+#if defined(MARL_DEV_FAST) && !defined(MARL_DEV_BIG)      /* development builds leave the kernels for N > 64 out (MARL_DEV_BIG: in) */
 #define MARL_LAUNCH_TEAM(N, kern, E, stream, ...) do { } while (0)
 #define MARL_DISPATCH_SLOTS(N, kern, grid, stream, ...) do { } while (0)
+#define MARL_DISPATCH_ROWS(N, kern, grid, stream, ...) do { } while (0)
 #else
 #define MARL_LAUNCH_TEAM(N, kern, E, stream, ...)                                                                   \
     do {                                                                                                            \
@@ -3223,6 +3287,13 @@ size_t workspace_bytes(int N, int E) {
         case 2: hipLaunchKernelGGL((kern<2>), grid, dim3(WAVE), sizeof(BigLds<2>), (hipStream_t)(stream), __VA_ARGS__); break; \
         case 3: hipLaunchKernelGGL((kern<3>), grid, dim3(WAVE), sizeof(BigLds<3>), (hipStream_t)(stream), __VA_ARGS__); break; \
         default: hipLaunchKernelGGL((kern<4>), grid, dim3(WAVE), sizeof(BigLds<4>), (hipStream_t)(stream), __VA_ARGS__); break; \
+    }
+// the same for kernels whose LDS is static (the Lanczos iteration on bit rows)
+#define MARL_DISPATCH_ROWS(N, kern, grid, stream, ...)                                                             \
+    switch (((N) + WAVE - 1) / WAVE) {                                                                             \
+        case 2: hipLaunchKernelGGL((kern<2>), grid, dim3(WAVE), 0, (hipStream_t)(stream), __VA_ARGS__); break;     \
+        case 3: hipLaunchKernelGGL((kern<3>), grid, dim3(WAVE), 0, (hipStream_t)(stream), __VA_ARGS__); break;     \
+        default: hipLaunchKernelGGL((kern<4>), grid, dim3(WAVE), 0, (hipStream_t)(stream), __VA_ARGS__); break;    \
     }
 #endif
 
@@ -3275,7 +3346,8 @@ enum { LANCZOS_AUTO_ENVS_PER_CU = 48 };
 // Priorities in the solve launch pay when the launch is about one round of the chip's wave slots (16 per CU; about 0.6
 // solve blocks per env): every slot then starts a solve at once and nothing follows, so what counts is that the four
 // solves of a SIMD end together.  With fewer blocks the SIMDs are not contended, with more the blocks that end early make
-// room for the next ones and holding them back costs.  On 256 CUs, one launch sequence, us per step with / without:
+// room for the next ones and holding them back costs -- which is the test the order kernel makes on the number of the
+// launch's items (SOLVE_PRIO_ITEMS_MIN / MAX).  On 256 CUs, one launch sequence, us per step with / without:
 // 4 096 envs 76.9 / 74.6, 6 144 envs 88.6 / 88.0, 7 168 envs 100.5 / 103.7, 8 192 envs 106.2 / 111.3, 9 216 envs
 // 118.9 / 117.8, 10 240 envs 133.0 / 127.5 (tools/prio_sweep.sh).
 enum { SOLVE_WAVES_PER_CU = 16 };          // the direct solve kernel: four waves on each of a compute unit's four SIMDs
@@ -3465,6 +3537,9 @@ static int step_launches(const MarlEnvParams* p, const MarlEnvState* s, const Ma
         if (s->workspace == nullptr || s->solve_partial == nullptr) return MARL_EINVAL;
         MARL_DISPATCH_SLOTS(p->N, env_step_big_kernel, dim3(s->E), stream, *p, *s, *io);
         if (before != nullptr && (rc = hip_check(hipEventRecord(before, (hipStream_t)stream))) != MARL_OK) return rc;
+        // the pending eigenproblems (65 .. 208 vertices): Lanczos iteration on the bit rows, one wave each; the team
+        // solver then takes what did not meet its bound (and everything, when the direct solver is asked for)
+        if (solver != MARL_LAMBDA2_DIRECT) { MARL_DISPATCH_ROWS(p->N, env_step_lanczos_rows_kernel, dim3(s->E), stream, *p, *s, *io); }
         MARL_LAUNCH_TEAM(p->N, env_step_team_kernel, s->E, stream, *p, *s, *io);
         if (after != nullptr && (rc = hip_check(hipEventRecord(after, (hipStream_t)stream))) != MARL_OK) return rc;
         return hip_check(hipGetLastError());
@@ -3651,6 +3726,10 @@ int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t* bits, double* l
         MARL_DISPATCH_SLOTS(N, lambda2_bits_big_kernel, dim3(E), stream, (int)N, bits, lambda2, (int)rounds,
                             (double*)workspace, pend);
         const size_t ld = (size_t)big_ld(N);
+        if (lanczos) {
+            MARL_DISPATCH_ROWS(N, lambda2_lanczos_rows_kernel, dim3(E), stream, (int)N, pend, (const double*)workspace, ld * ld,
+                               lambda2, (int)rounds);
+        }
         MARL_LAUNCH_TEAM(N, lambda2_team_kernel, E, stream, (int)N, (const int*)pend, (const double*)workspace,
                          ld * ld, lambda2, (int)rounds);
         return hip_check(hipGetLastError());

@@ -21,8 +21,11 @@ def _lambda2(adj, rounds):
     E, N, _ = adj.shape
     bits = torch.from_numpy(np.stack([orc.pack_rows(a) for a in adj]).view(np.int32)).cuda().contiguous()
     out = torch.zeros(E, dtype=torch.float64, device="cuda")
-    _lib.check(_lib.load().marl_lambda2_from_bits(N, E, bits.data_ptr(), out.data_ptr(), rounds, None,
-                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    lib = _lib.load()
+    nb = lib.marl_lambda2_workspace_bytes(N, E)
+    ws = torch.zeros(max(nb, 8), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.marl_lambda2_from_bits(N, E, bits.data_ptr(), out.data_ptr(), rounds, ws.data_ptr() if nb else None,
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     return out.cpu().numpy()
 
@@ -60,6 +63,21 @@ def _random_graphs(rng, n, count):
 def test_lanczos_lambda2_against_lapack(n):
     rng = np.random.RandomState(1000 + n)
     adj = _random_graphs(rng, n, 96)
+    got = _lambda2(adj, _lib.LAMBDA2_LANCZOS)
+    direct = _lambda2(adj, _lib.LAMBDA2_DIRECT)
+    for e in range(adj.shape[0]):
+        a = adj[e].astype(np.float64)
+        want = np.linalg.eigvalsh(np.diag(a.sum(1)) - a)[1]
+        assert abs(got[e] - want) <= 1e-8 * max(1.0, abs(want)), (n, e, got[e], want)
+        assert abs(direct[e] - want) <= 2e-9 * max(1.0, abs(want)), (n, e, direct[e], want)
+
+
+@pytest.mark.parametrize("n", [65, 66, 100, 127, 128, 129, 150, 192, 193, 200, 208])
+def test_lanczos_on_bit_rows_against_lapack(n):
+    """Beyond 64 vertices the iteration works on the adjacency bits themselves (one wave per graph; graphs denser than
+    one half through their complement); what does not meet its bound goes to the team solver.  Same bar as below 64."""
+    rng = np.random.RandomState(2000 + n)
+    adj = _random_graphs(rng, n, 36)
     got = _lambda2(adj, _lib.LAMBDA2_LANCZOS)
     direct = _lambda2(adj, _lib.LAMBDA2_DIRECT)
     for e in range(adj.shape[0]):
