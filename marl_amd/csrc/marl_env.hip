@@ -2083,6 +2083,13 @@ __host__ __device__ inline int* workspace_pending(double* ws, int N, int E) {
     const size_t ld = (size_t)big_ld(N);
     return reinterpret_cast<int*>(ws + (size_t)E * ld * ld);
 }
+// ... then the envs that the Lanczos launch leaves to the team solver: a count and up to TEAM_LIST_MAX env indices (the
+// team launch that follows it has that many workgroups instead of one per env, which at 50 ns per workgroup that only
+// looks and leaves would cost more than its solves; a failure beyond the list is solved by the wave that met it).
+constexpr int TEAM_LIST_MAX = 1024;
+__host__ __device__ inline int* workspace_team_list(double* ws, int N, int E) {
+    return workspace_pending(ws, N, E) + (((size_t)E + 63) & ~(size_t)63);
+}
 
 template <int S>
 __device__ __forceinline__ uint64_t word_mask(int n, int k) {      // valid vertex bits of word k
@@ -2270,92 +2277,13 @@ __device__ __forceinline__ void expand_big(const uint64_t (&rows)[S][S], const u
     }
 }
 
-template <int S>
-__device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int n, int lane, BigLds<S>& L, int rounds,
-                                              double* As, int* pending = nullptr) {
-    // `pending` non-null: an eigenproblem of 65..TEAM_MAX_NP vertices is not solved here; its compacted
-    // complement rows (np x S words) go to the head of `As`, *pending = np, and the team kernel
-    // (one workgroup of 512 threads per env, matrix in registers) takes over.  *pending = 0 otherwise.
-    if (pending) *pending = 0;
-    if (n <= 1) return 0.0;
-    uint64_t touched[S];
-    int deg[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        int d = 0;
-#pragma unroll
-        for (int k = 0; k < S; ++k) d += __popcll(rows[s][k]);
-        deg[s] = d;
-        touched[s] = ballot64(s * WAVE + lane < n && d < n - 1);
-    }
-    if (!any_words<S>(touched)) return (double)n;
-    {   // connectivity from vertex 0
-        uint64_t comp[S], frontier[S], hit[S];
-#pragma unroll
-        for (int k = 0; k < S; ++k) { comp[k] = 0; frontier[k] = 0; }
-        comp[0] = 1ull; frontier[0] = 1ull;
-        while (any_words<S>(frontier)) {
-            expand_big<S>(rows, frontier, hit);
-#pragma unroll
-            for (int k = 0; k < S; ++k) { const uint64_t nw = hit[k] & ~comp[k]; comp[k] |= nw; frontier[k] = nw; }
-        }
-        bool all = true;
-#pragma unroll
-        for (int k = 0; k < S; ++k) all = all && (comp[k] == word_mask<S>(n, k));
-        if (!all) return 0.0;
-    }
-    int np = 0;
-    int before[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) { before[s] = np; np += __popcll(touched[s]); }
-    // compact the complement rows of the touched vertices: bit r of the new row = touched vertex of rank r
-    WSYNC();
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        uint64_t cw[S];
-#pragma unroll
-        for (int q = 0; q < S; ++q) cw[q] = 0;
-        int r = 0;
-#pragma unroll
-        for (int k = 0; k < S; ++k) {
-            uint64_t cfull = ~rows[s][k] & word_mask<S>(n, k) & touched[k];
-            if (k == s) cfull &= ~(1ull << lane);
-            uint64_t t = touched[k];
-            while (t) {                         // one step per run of consecutive touched vertices (t, r: wave-uniform)
-                const int a = __ffsll((unsigned long long)t) - 1;
-                const uint64_t inv = ~(t >> a);                      // zero bits mark the end of the run
-                const int len = inv ? __ffsll((unsigned long long)inv) - 1 : 64;
-                const uint64_t ones = (len >= 64) ? ~0ull : ((1ull << len) - 1);
-                const uint64_t run = (cfull >> a) & ones;
-                const int qd = r >> 6, sh = r & 63;
-#pragma unroll
-                for (int q = 0; q < S; ++q) {
-                    if (q == qd) cw[q] |= run << sh;
-                    if (q == qd + 1 && sh != 0) cw[q] |= run >> (64 - sh);      // the part of the run that spills over
-                }
-                r += len;
-                t = (a + len >= 64) ? 0ull : (t & ~(ones << a));
-            }
-        }
-        if ((touched[s] >> lane) & 1ull) {
-            const int rank = before[s] + __popcll(touched[s] & ((1ull << lane) - 1));
-#pragma unroll
-            for (int q = 0; q < S; ++q) L.xfer[rank * S + q] = cw[q];
-        }
-    }
-    WSYNC();
-    if (np <= WAVE) {
-        const uint64_t crow = (lane < np) ? L.xfer[lane * S] : 0ull;
-        return (double)n - mu_max_in_wave<WAVE>(crow, np, lane, L, rounds, (double)n);
-    }
-    if (pending != nullptr && np <= TEAM_MAX_NP) {
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(As);
-        for (int k = lane; k < np * S; k += WAVE) out[k] = L.xfer[k];
-        *pending = np;
-        return 0.0;
-    }
-    // ---- n' > 64: matrix in the global workspace, element (r, c) at As[c*ld + r]; lane owns rows r = s*64+lane
-    const int ld = big_ld(n);
+// mu_max of the complement Laplacian of np <= S * 64 vertices by ONE wave, the matrix in global memory: element (r, c) at
+// As[c * ld + r], lane t owns rows t, 64 + t, ...; w[s][q]: word q of the compacted row s * 64 + lane.  The slowest of
+// the solvers (every Householder step reads and writes the matrix), for what fits no other: more vertices than the team
+// solver holds, or a Lanczos failure that found the team's list full.  L: any LDS block with de[S * 64], uvec, qvec.
+template <int S, class LDS>
+__device__ __forceinline__ double mu_max_global_wave(const uint64_t (&w)[S][S], int np, int lane, LDS& L, int rounds,
+                                                     double* As, int ld) {
     int dmax = 0;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -2364,7 +2292,7 @@ __device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int 
             uint64_t cw[S];
             int cdeg = 0;
 #pragma unroll
-            for (int q = 0; q < S; ++q) { cw[q] = L.xfer[r * S + q]; cdeg += __popcll(cw[q]); }
+            for (int q = 0; q < S; ++q) { cw[q] = w[s][q]; cdeg += __popcll(cw[q]); }
             dmax = max(dmax, cdeg);
 #pragma unroll
             for (int q = 0; q < S; ++q) {
@@ -2453,7 +2381,100 @@ __device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int 
     WSYNC();
     const double lo = (double)(dmax + 1) * (1.0 - 1e-13) - 1e-13;
     const double hi = (double)min(np, 2 * dmax) * (1.0 + 1e-13) + 1e-13;
-    return (double)n - sturm_largest_wave(L, np, lane, lo, hi, rounds + 1);
+    return sturm_largest_wave(L, np, lane, lo, hi, rounds + 1);
+}
+
+template <int S>
+__device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int n, int lane, BigLds<S>& L, int rounds,
+                                              double* As, int* pending = nullptr) {
+    // `pending` non-null: an eigenproblem of 65..TEAM_MAX_NP vertices is not solved here; its compacted
+    // complement rows (np x S words) go to the head of `As`, *pending = np, and the team kernel
+    // (one workgroup of 512 threads per env, matrix in registers) takes over.  *pending = 0 otherwise.
+    if (pending) *pending = 0;
+    if (n <= 1) return 0.0;
+    uint64_t touched[S];
+    int deg[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        int d = 0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) d += __popcll(rows[s][k]);
+        deg[s] = d;
+        touched[s] = ballot64(s * WAVE + lane < n && d < n - 1);
+    }
+    if (!any_words<S>(touched)) return (double)n;
+    {   // connectivity from vertex 0
+        uint64_t comp[S], frontier[S], hit[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) { comp[k] = 0; frontier[k] = 0; }
+        comp[0] = 1ull; frontier[0] = 1ull;
+        while (any_words<S>(frontier)) {
+            expand_big<S>(rows, frontier, hit);
+#pragma unroll
+            for (int k = 0; k < S; ++k) { const uint64_t nw = hit[k] & ~comp[k]; comp[k] |= nw; frontier[k] = nw; }
+        }
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < S; ++k) all = all && (comp[k] == word_mask<S>(n, k));
+        if (!all) return 0.0;
+    }
+    int np = 0;
+    int before[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) { before[s] = np; np += __popcll(touched[s]); }
+    // compact the complement rows of the touched vertices: bit r of the new row = touched vertex of rank r
+    WSYNC();
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        uint64_t cw[S];
+#pragma unroll
+        for (int q = 0; q < S; ++q) cw[q] = 0;
+        int r = 0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            uint64_t cfull = ~rows[s][k] & word_mask<S>(n, k) & touched[k];
+            if (k == s) cfull &= ~(1ull << lane);
+            uint64_t t = touched[k];
+            while (t) {                         // one step per run of consecutive touched vertices (t, r: wave-uniform)
+                const int a = __ffsll((unsigned long long)t) - 1;
+                const uint64_t inv = ~(t >> a);                      // zero bits mark the end of the run
+                const int len = inv ? __ffsll((unsigned long long)inv) - 1 : 64;
+                const uint64_t ones = (len >= 64) ? ~0ull : ((1ull << len) - 1);
+                const uint64_t run = (cfull >> a) & ones;
+                const int qd = r >> 6, sh = r & 63;
+#pragma unroll
+                for (int q = 0; q < S; ++q) {
+                    if (q == qd) cw[q] |= run << sh;
+                    if (q == qd + 1 && sh != 0) cw[q] |= run >> (64 - sh);      // the part of the run that spills over
+                }
+                r += len;
+                t = (a + len >= 64) ? 0ull : (t & ~(ones << a));
+            }
+        }
+        if ((touched[s] >> lane) & 1ull) {
+            const int rank = before[s] + __popcll(touched[s] & ((1ull << lane) - 1));
+#pragma unroll
+            for (int q = 0; q < S; ++q) L.xfer[rank * S + q] = cw[q];
+        }
+    }
+    WSYNC();
+    if (np <= WAVE) {
+        const uint64_t crow = (lane < np) ? L.xfer[lane * S] : 0ull;
+        return (double)n - mu_max_in_wave<WAVE>(crow, np, lane, L, rounds, (double)n);
+    }
+    if (pending != nullptr && np <= TEAM_MAX_NP) {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(As);
+        for (int k = lane; k < np * S; k += WAVE) out[k] = L.xfer[k];
+        *pending = np;
+        return 0.0;
+    }
+    // ---- n' beyond the team solver: one wave, matrix in the global workspace
+    uint64_t w[S][S];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int q = 0; q < S; ++q) w[s][q] = (s * WAVE + lane < np) ? L.xfer[(s * WAVE + lane) * S + q] : 0ull;
+    return (double)n - mu_max_global_wave<S>(w, np, lane, L, rounds, As, big_ld(n));
 }
 
 // DBSCAN + centroids for S slots per lane; labels by reference, tables in L.cx/L.cy/L.csz.
@@ -2685,6 +2706,7 @@ __global__ __launch_bounds__(WAVE) void env_step_big_kernel(MarlEnvParams P, Mar
         io.truncated[e] = (uint8_t)(step >= P.max_steps);
         if (io.avg_power_dbm) io.avg_power_dbm[e] = avgp;
         workspace_pending(St.workspace, n, St.E)[e] = pending;
+        if (e == 0) workspace_team_list(St.workspace, n, St.E)[0] = 0;
         if (pending) {
             double* part = St.solve_partial + (size_t)e * 4;
             part[0] = rw.d2; part[1] = rw.d3; part[2] = (double)rw.r3; part[3] = rw.d5;
@@ -3024,9 +3046,14 @@ __device__ __forceinline__ double mu_max_team(const unsigned long long* rows, in
 // Stage op: lambda2 for the envs the wave kernel left pending (pend[e] = np > 0).
 template <int CH, int S>
 __global__ __launch_bounds__(TEAM_THREADS) void lambda2_team_kernel(int n, const int* pend, const double* ws,
-                                                                    size_t ws_stride, double* lambda2, int rounds) {
+                                                                    size_t ws_stride, double* lambda2, int rounds,
+                                                                    const int* team_list) {
     __shared__ TeamLds<CH> L;
-    const int e = blockIdx.x;
+    int e = blockIdx.x;
+    if (team_list != nullptr) {                 // after the Lanczos launch: workgroup b takes entry b of what it left
+        if (e >= min(team_list[0], TEAM_LIST_MAX)) return;
+        e = team_list[1 + e];
+    }
     const int np = pend[e];
     if (np <= 0) return;
     const double mu = mu_max_team<CH, S>(reinterpret_cast<const unsigned long long*>(ws + (size_t)e * ws_stride), np, L, rounds);
@@ -3036,9 +3063,15 @@ __global__ __launch_bounds__(TEAM_THREADS) void lambda2_team_kernel(int n, const
 // Second launch of a step for 64 < N <= 256: the pending eigenproblems, one workgroup each, then the
 // reward of that env (term 1 and the clipped sum, as env_step_solve_kernel does for N <= 64).
 template <int CH, int S>
-__global__ __launch_bounds__(TEAM_THREADS) void env_step_team_kernel(MarlEnvParams P, MarlEnvState St, MarlStepIO io) {
+__global__ __launch_bounds__(TEAM_THREADS) void env_step_team_kernel(MarlEnvParams P, MarlEnvState St, MarlStepIO io,
+                                                                     int from_list) {
     __shared__ TeamLds<CH> L;
-    const int e = blockIdx.x;
+    int e = blockIdx.x;
+    if (from_list) {                            // after the Lanczos launch: workgroup b takes entry b of what it left
+        const int* team_list = workspace_team_list(St.workspace, P.N, St.E);
+        if (e >= min(team_list[0], TEAM_LIST_MAX)) return;
+        e = team_list[1 + e];
+    }
     const int np = workspace_pending(St.workspace, P.N, St.E)[e];
     if (np <= 0) return;
     const size_t ld = (size_t)big_ld(P.N);
@@ -3058,17 +3091,62 @@ __global__ __launch_bounds__(TEAM_THREADS) void env_step_team_kernel(MarlEnvPara
 // Between the two launches of a step for 64 < N <= 256 (and of the stage op): the Lanczos iteration on the pending
 // eigenproblems, one wave each, straight from the compacted bit rows.  A problem that meets its bound is finished here
 // (pending count cleared: the team kernel's workgroup for it leaves at once); the others stay for the direct solver.
+// LDS of the global-memory solver where the Lanczos kernels need it (they share one block of LDS)
+template <int S>
+struct GlobalSolveLds {
+    double2 de[S * WAVE];
+    double uvec[S * WAVE], qvec[S * WAVE];
+};
+template <int S>
+constexpr size_t rows_lds_bytes() {
+    return sizeof(LanczosRowsLds<S>) > sizeof(GlobalSolveLds<S>) ? sizeof(LanczosRowsLds<S>) : sizeof(GlobalSolveLds<S>);
+}
+// The Lanczos iteration on env e's pending eigenproblem.  True: mu holds mu_max.  False: not within its bound, and the
+// env is on the team solver's list now -- unless that was full, in which case the wave has solved it by itself through
+// global memory (true again).
+template <int S>
+__device__ __forceinline__ bool rows_solve(double* region, int ld, int np, int lane, double nfull, unsigned char* raw, int rounds,
+                                           int e, int* team_list, double& mu) {
+    const unsigned long long* rows = reinterpret_cast<const unsigned long long*>(region);
+    if (mu_max_lanczos_rows<S>(rows, np, lane, nfull, *reinterpret_cast<LanczosRowsLds<S>*>(raw), rounds, mu)) return true;
+    int at = 0;
+    if (lane == 0) at = atomicAdd(&team_list[0], 1);
+    at = __builtin_amdgcn_readfirstlane(at);
+    if (at < TEAM_LIST_MAX) {
+        if (lane == 0) team_list[1 + at] = e;
+        return false;
+    }
+    uint64_t w[S][S];                        // the rows lie where the matrix goes: into registers first
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int q = 0; q < S; ++q) w[s][q] = (s * WAVE + lane < np) ? rows[(size_t)(s * WAVE + lane) * S + q] : 0ull;
+    WSYNC();
+    mu = mu_max_global_wave<S>(w, np, lane, *reinterpret_cast<GlobalSolveLds<S>*>(raw), rounds, region, ld);
+    return true;
+}
+
+// Between the two launches of a step for 64 < N <= 256 (and of the stage op): the Lanczos iteration on the pending
+// eigenproblems, one wave each, straight from the compacted bit rows.  A problem that meets its bound is finished here
+// (pending count cleared); the others go on the list that the team launch works through.
+//
+// The launch is as long as its slowest solve started late, and the slow ones are the large ones (more vertices, more
+// steps).  The grid therefore passes over the envs ROWS_PASSES times -- workgroup b looks at env b mod E and takes it
+// only in the pass of its size class, largest first -- so that every large problem is running before the first small
+// one starts; a workgroup that only looks costs a few nanoseconds.
+constexpr int ROWS_PASSES = 3;
+__device__ __forceinline__ int rows_pass_of(int np, int n) { return 4 * np >= 3 * n ? 0 : (2 * np >= n ? 1 : 2); }
 template <int S>
 __global__ __launch_bounds__(WAVE) void env_step_lanczos_rows_kernel(MarlEnvParams P, MarlEnvState St, MarlStepIO io) {
-    __shared__ LanczosRowsLds<S> L;
-    const int e = blockIdx.x, lane = threadIdx.x;
+    __shared__ __align__(16) unsigned char raw[rows_lds_bytes<S>()];
+    const int e = blockIdx.x % St.E, lane = threadIdx.x;
     int* pend = workspace_pending(St.workspace, P.N, St.E);
     const int np = pend[e];
-    if (np <= 0) return;
-    const size_t ld = (size_t)big_ld(P.N);
+    if (np <= 0 || rows_pass_of(np, P.N) != (int)blockIdx.x / St.E) return;
+    const int ld = big_ld(P.N);
     double mu;
-    if (!mu_max_lanczos_rows<S>(reinterpret_cast<const unsigned long long*>(St.workspace + (size_t)e * ld * ld), np, lane,
-                                (double)P.N, L, P.lambda2_rounds, mu))
+    if (!rows_solve<S>(St.workspace + (size_t)e * ld * ld, ld, np, lane, (double)P.N, raw, P.lambda2_rounds, e,
+                       workspace_team_list(St.workspace, P.N, St.E), mu))
         return;
     if (lane == 0) {
         const double lam = (double)P.N - mu;
@@ -3082,16 +3160,14 @@ __global__ __launch_bounds__(WAVE) void env_step_lanczos_rows_kernel(MarlEnvPara
     }
 }
 template <int S>
-__global__ __launch_bounds__(WAVE) void lambda2_lanczos_rows_kernel(int n, int* pend, const double* ws, size_t ws_stride,
+__global__ __launch_bounds__(WAVE) void lambda2_lanczos_rows_kernel(int n, int E, int* pend, double* ws, int ld, int* team_list,
                                                                     double* lambda2, int rounds) {
-    __shared__ LanczosRowsLds<S> L;
-    const int e = blockIdx.x, lane = threadIdx.x;
+    __shared__ __align__(16) unsigned char raw[rows_lds_bytes<S>()];
+    const int e = blockIdx.x % E, lane = threadIdx.x;
     const int np = pend[e];
-    if (np <= 0) return;
+    if (np <= 0 || rows_pass_of(np, n) != (int)blockIdx.x / E) return;
     double mu;
-    if (!mu_max_lanczos_rows<S>(reinterpret_cast<const unsigned long long*>(ws + (size_t)e * ws_stride), np, lane, (double)n, L,
-                                rounds, mu))
-        return;
+    if (!rows_solve<S>(ws + (size_t)e * ld * ld, ld, np, lane, (double)n, raw, rounds, e, team_list, mu)) return;
     if (lane == 0) {
         lambda2[e] = (double)n - mu;
         pend[e] = 0;
@@ -3128,6 +3204,7 @@ __global__ __launch_bounds__(WAVE) void lambda2_bits_big_kernel(int n, const uin
     if (lane == 0) {
         pend[e] = pending;
         if (!pending) lambda2[e] = lam;
+        if (e == 0) pend[((size_t)gridDim.x + 63) & ~(size_t)63] = 0;        // the team solver's list (workspace_team_list): empty
     }
 }
 
@@ -3264,7 +3341,8 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 size_t workspace_bytes(int N, int E) {
     if (N <= WAVE) return 0;
     const size_t ld = (size_t)big_ld(N);
-    return (size_t)E * ld * ld * sizeof(double) + align256((size_t)E * sizeof(int));   // + pending list of the team solver
+    return (size_t)E * ld * ld * sizeof(double) + align256((size_t)E * sizeof(int)) +   // + pending list of the team solver
+           align256((size_t)(TEAM_LIST_MAX + 1) * sizeof(int));                           // + what the Lanczos launch leaves to it
 }
 
 
@@ -3539,8 +3617,12 @@ static int step_launches(const MarlEnvParams* p, const MarlEnvState* s, const Ma
         if (before != nullptr && (rc = hip_check(hipEventRecord(before, (hipStream_t)stream))) != MARL_OK) return rc;
         // the pending eigenproblems (65 .. 208 vertices): Lanczos iteration on the bit rows, one wave each; the team
         // solver then takes what did not meet its bound (and everything, when the direct solver is asked for)
-        if (solver != MARL_LAMBDA2_DIRECT) { MARL_DISPATCH_ROWS(p->N, env_step_lanczos_rows_kernel, dim3(s->E), stream, *p, *s, *io); }
-        MARL_LAUNCH_TEAM(p->N, env_step_team_kernel, s->E, stream, *p, *s, *io);
+        if (solver != MARL_LAMBDA2_DIRECT) {
+            MARL_DISPATCH_ROWS(p->N, env_step_lanczos_rows_kernel, dim3(s->E * ROWS_PASSES), stream, *p, *s, *io);
+            MARL_LAUNCH_TEAM(p->N, env_step_team_kernel, (s->E < TEAM_LIST_MAX ? s->E : TEAM_LIST_MAX), stream, *p, *s, *io, 1);
+        } else {
+            MARL_LAUNCH_TEAM(p->N, env_step_team_kernel, s->E, stream, *p, *s, *io, 0);
+        }
         if (after != nullptr && (rc = hip_check(hipEventRecord(after, (hipStream_t)stream))) != MARL_OK) return rc;
         return hip_check(hipGetLastError());
     }
@@ -3727,11 +3809,15 @@ int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t* bits, double* l
                             (double*)workspace, pend);
         const size_t ld = (size_t)big_ld(N);
         if (lanczos) {
-            MARL_DISPATCH_ROWS(N, lambda2_lanczos_rows_kernel, dim3(E), stream, (int)N, pend, (const double*)workspace, ld * ld,
+            int* team_list = workspace_team_list((double*)workspace, N, E);
+            MARL_DISPATCH_ROWS(N, lambda2_lanczos_rows_kernel, dim3(E * ROWS_PASSES), stream, (int)N, (int)E, pend, (double*)workspace, (int)ld, team_list,
                                lambda2, (int)rounds);
+            MARL_LAUNCH_TEAM(N, lambda2_team_kernel, (E < TEAM_LIST_MAX ? E : TEAM_LIST_MAX), stream, (int)N, (const int*)pend,
+                             (const double*)workspace, ld * ld, lambda2, (int)rounds, (const int*)team_list);
+        } else {
+            MARL_LAUNCH_TEAM(N, lambda2_team_kernel, E, stream, (int)N, (const int*)pend, (const double*)workspace,
+                             ld * ld, lambda2, (int)rounds, (const int*)nullptr);
         }
-        MARL_LAUNCH_TEAM(N, lambda2_team_kernel, E, stream, (int)N, (const int*)pend, (const double*)workspace,
-                         ld * ld, lambda2, (int)rounds);
         return hip_check(hipGetLastError());
     }
     if (lanczos && N > 32) {
