@@ -87,6 +87,33 @@ def test_lanczos_on_bit_rows_against_lapack(n):
         assert abs(direct[e] - want) <= 2e-9 * max(1.0, abs(want)), (n, e, direct[e], want)
 
 
+def test_lanczos_failures_beyond_the_team_list_are_solved_in_place():
+    """What the iteration does not settle goes on a list of 1 024 envs for the team solver; a failure that finds the list
+    full is solved by its own wave through global memory.  1 200 copies of a graph whose complement is a path (the top
+    of its spectrum, 2 - 2 cos(k pi / n), is a cluster with gaps of 1e-3: hundreds of steps) fill the list and overflow it."""
+    n, E = 130, 1200
+    comp = np.zeros((n, n), dtype=bool)
+    i = np.arange(n - 1)
+    comp[i, i + 1] = comp[i + 1, i] = True
+    adj = ~comp
+    np.fill_diagonal(adj, False)
+    a = adj.astype(np.float64)
+    want = np.linalg.eigvalsh(np.diag(a.sum(1)) - a)[1]
+    bits = torch.from_numpy(np.repeat(orc.pack_rows(adj)[None], E, 0).view(np.int32)).cuda().contiguous()
+    lib = _lib.load()
+    nb = lib.marl_lambda2_workspace_bytes(n, E)
+    ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(E, dtype=torch.float64, device="cuda")
+    _lib.check(lib.marl_lambda2_from_bits(n, E, bits.data_ptr(), out.data_ptr(), _lib.LAMBDA2_LANCZOS, ws.data_ptr(),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    ld = (n + 7) // 8 * 8
+    listed = int(ws[E * ld * ld * 8 + (E + 63) // 64 * 64 * 4:][:4].view(torch.int32)[0])
+    assert listed == E, listed                       # every copy failed its bound: 1 024 on the list, the rest in place
+    got = out.cpu().numpy()
+    assert np.all(np.abs(got - want) <= 2e-9 * max(1.0, abs(want))), (got.min(), got.max(), want)
+
+
 def test_lanczos_closed_forms():
     """K_n minus a few edges, path and cycle (reference tests/test_laplacian.py:251-310) at 50 and 64 vertices."""
     for n in (50, 64):
