@@ -39,8 +39,9 @@ def stats(out, dbp):
 
 
 STEP_KERNELS = ("env_step_front_kernel", "solve_order_kernel", "env_step_solve_kernel", "env_step_solve_prio_kernel",
-                "env_step_solve_lanczos_kernel", "env_step_big_kernel", "env_step_team_kernel")
-SOLVE_KERNELS = ("env_step_solve_kernel", "env_step_solve_prio_kernel", "env_step_solve_lanczos_kernel", "env_step_team_kernel")
+                "env_step_solve_lanczos_kernel", "env_step_big_kernel", "env_step_lanczos_rows_kernel", "env_step_team_kernel")
+SOLVE_KERNELS = ("env_step_solve_kernel", "env_step_solve_prio_kernel", "env_step_solve_lanczos_kernel",
+                 "env_step_lanczos_rows_kernel", "env_step_team_kernel")
 
 
 def pmc(out, dbs):
@@ -79,9 +80,9 @@ def summary(out, stats_csv, pmc_json=None):
     for row in csv.DictReader(open(stats_csv)):
         if row["AverageNs"]:
             res["kernel_avg_us"][row["Name"]] = float(row["AverageNs"]) / 1e3
-    for k, v in res["kernel_avg_us"].items():
-        if k.startswith(SOLVE_KERNELS):
-            res["solve_kernel_us"] = v
+    solve = [v for k, v in res["kernel_avg_us"].items() if k.startswith(SOLVE_KERNELS)]
+    if solve:
+        res["solve_kernel_us"] = sum(solve)        # N > 64: the Lanczos launch and the team launch after it
     if pmc_json:
         p = json.load(open(pmc_json))
         ps = p["per_step"]
