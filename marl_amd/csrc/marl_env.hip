@@ -2087,6 +2087,9 @@ __host__ __device__ inline int* workspace_pending(double* ws, int N, int E) {
 // team launch that follows it has that many workgroups instead of one per env, which at 50 ns per workgroup that only
 // looks and leaves would cost more than its solves; a failure beyond the list is solved by the wave that met it).
 constexpr int TEAM_LIST_MAX = 1024;
+// Set by marl_env_step in the parameter copy its kernels get (never by a caller): the Lanczos launch on bit rows follows
+// the front launch, so eigenproblems beyond the team solver's size are left pending too.
+constexpr int STAGE_ROWS_FOLLOW = 0x100;
 __host__ __device__ inline int* workspace_team_list(double* ws, int N, int E) {
     return workspace_pending(ws, N, E) + (((size_t)E + 63) & ~(size_t)63);
 }
@@ -2386,7 +2389,7 @@ __device__ __forceinline__ double mu_max_global_wave(const uint64_t (&w)[S][S], 
 
 template <int S>
 __device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int n, int lane, BigLds<S>& L, int rounds,
-                                              double* As, int* pending = nullptr) {
+                                              double* As, int* pending = nullptr, bool rows_follow = false) {
     // `pending` non-null: an eigenproblem of 65..TEAM_MAX_NP vertices is not solved here; its compacted
     // complement rows (np x S words) go to the head of `As`, *pending = np, and the team kernel
     // (one workgroup of 512 threads per env, matrix in registers) takes over.  *pending = 0 otherwise.
@@ -2462,7 +2465,9 @@ __device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int 
         const uint64_t crow = (lane < np) ? L.xfer[lane * S] : 0ull;
         return (double)n - mu_max_in_wave<WAVE>(crow, np, lane, L, rounds, (double)n);
     }
-    if (pending != nullptr && np <= TEAM_MAX_NP) {
+    // (rows_follow: the Lanczos launch on bit rows comes next, which takes any size up to S * 64 and, should it fail
+    // on a problem beyond the team solver, falls back to the global-memory solver below by itself)
+    if (pending != nullptr && (np <= TEAM_MAX_NP || rows_follow)) {
         unsigned long long* out = reinterpret_cast<unsigned long long*>(As);
         for (int k = lane; k < np * S; k += WAVE) out[k] = L.xfer[k];
         *pending = np;
@@ -2687,7 +2692,8 @@ __global__ __launch_bounds__(WAVE) void env_step_big_kernel(MarlEnvParams P, Mar
     // eigenproblems of 65..208 vertices are left to env_step_team_kernel, which also finishes the reward
     const int ld = big_ld(n);
     int pending;
-    const double lam = lambda2_big<S>(adj, n, lane, L, P.lambda2_rounds, St.workspace + (size_t)e * ld * ld, &pending);
+    const double lam = lambda2_big<S>(adj, n, lane, L, P.lambda2_rounds, St.workspace + (size_t)e * ld * ld, &pending,
+                                      (P.stage_flags & STAGE_ROWS_FOLLOW) != 0);
     const double lam0 = St.lambda2_initial[e];
     const RewardOut rw = reward_obs_wave(P, n, m, lane, L, eband, num, ncent, lam, lam0, raw_vx, raw_vy);
     if (lane < m && io.obs) {
@@ -3109,10 +3115,10 @@ __device__ __forceinline__ bool rows_solve(double* region, int ld, int np, int l
                                            int e, int* team_list, double& mu) {
     const unsigned long long* rows = reinterpret_cast<const unsigned long long*>(region);
     if (mu_max_lanczos_rows<S>(rows, np, lane, nfull, *reinterpret_cast<LanczosRowsLds<S>*>(raw), rounds, mu)) return true;
-    int at = 0;
-    if (lane == 0) at = atomicAdd(&team_list[0], 1);
+    int at = TEAM_LIST_MAX;                  // (a problem beyond the team solver's size does not ask for a place)
+    if (lane == 0 && np <= TEAM_MAX_NP) at = atomicAdd(&team_list[0], 1);
     at = __builtin_amdgcn_readfirstlane(at);
-    if (at < TEAM_LIST_MAX) {
+    if (at < TEAM_LIST_MAX && np <= TEAM_MAX_NP) {
         if (lane == 0) team_list[1 + at] = e;
         return false;
     }
@@ -3176,7 +3182,7 @@ __global__ __launch_bounds__(WAVE) void lambda2_lanczos_rows_kernel(int n, int E
 
 template <int S>
 __global__ __launch_bounds__(WAVE) void lambda2_bits_big_kernel(int n, const uint32_t* bits, double* lambda2, int rounds,
-                                                                double* ws, int* pend) {
+                                                                double* ws, int* pend, int rows_follow) {
     extern __shared__ __align__(16) unsigned char smem[];
     BigLds<S>& L = *reinterpret_cast<BigLds<S>*>(smem);
     const int e = blockIdx.x, lane = threadIdx.x;
@@ -3200,7 +3206,7 @@ __global__ __launch_bounds__(WAVE) void lambda2_bits_big_kernel(int n, const uin
     }
     const int ld = big_ld(n);
     int pending;
-    const double lam = lambda2_big<S>(rows, n, lane, L, rounds, ws + (size_t)e * ld * ld, &pending);
+    const double lam = lambda2_big<S>(rows, n, lane, L, rounds, ws + (size_t)e * ld * ld, &pending, rows_follow != 0);
     if (lane == 0) {
         pend[e] = pending;
         if (!pending) lambda2[e] = lam;
@@ -3613,6 +3619,7 @@ static int step_launches(const MarlEnvParams* p, const MarlEnvState* s, const Ma
     p = &q;
     if (p->N > WAVE) {
         if (s->workspace == nullptr || s->solve_partial == nullptr) return MARL_EINVAL;
+        if (solver != MARL_LAMBDA2_DIRECT) q.stage_flags |= STAGE_ROWS_FOLLOW;
         MARL_DISPATCH_SLOTS(p->N, env_step_big_kernel, dim3(s->E), stream, *p, *s, *io);
         if (before != nullptr && (rc = hip_check(hipEventRecord(before, (hipStream_t)stream))) != MARL_OK) return rc;
         // the pending eigenproblems (65 .. 208 vertices): Lanczos iteration on the bit rows, one wave each; the team
@@ -3806,7 +3813,7 @@ int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t* bits, double* l
         if (workspace == nullptr) return MARL_EINVAL;
         int* pend = workspace_pending((double*)workspace, N, E);
         MARL_DISPATCH_SLOTS(N, lambda2_bits_big_kernel, dim3(E), stream, (int)N, bits, lambda2, (int)rounds,
-                            (double*)workspace, pend);
+                            (double*)workspace, pend, (int)lanczos);
         const size_t ld = (size_t)big_ld(N);
         if (lanczos) {
             int* team_list = workspace_team_list((double*)workspace, N, E);

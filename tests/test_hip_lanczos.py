@@ -72,7 +72,7 @@ def test_lanczos_lambda2_against_lapack(n):
         assert abs(direct[e] - want) <= 2e-9 * max(1.0, abs(want)), (n, e, direct[e], want)
 
 
-@pytest.mark.parametrize("n", [65, 66, 100, 127, 128, 129, 150, 192, 193, 200, 208])
+@pytest.mark.parametrize("n", [65, 66, 100, 127, 128, 129, 150, 192, 193, 200, 208, 209, 224, 256])
 def test_lanczos_on_bit_rows_against_lapack(n):
     """Beyond 64 vertices the iteration works on the adjacency bits themselves (one wave per graph; graphs denser than
     one half through their complement); what does not meet its bound goes to the team solver.  Same bar as below 64."""
