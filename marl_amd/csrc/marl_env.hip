@@ -222,15 +222,26 @@ __device__ __forceinline__ void enemy_spawn(const MarlEnvParams& P, const MarlEn
 }
 
 // ------------------------------------------------------------------ LDS layout of one env
+// 5 120 bytes up to the solver's part: 32 envs per compute unit (160 KB), eight waves per SIMD.  A cluster table has
+// at most 64 entries for 64 points (min_samples = 1: every point a cluster and none noise; otherwise clusters of two or
+// more, and one entry for the noise).  The previous centroids, which only a re-clustering step looks at, lie in the
+// storage of two arrays that are written after it.
 struct WaveLds {
     double2 sxy[WAVE];                // enemy positions (x, y): one 16-byte read per enemy in the pair loops
-    float sxf[WAVE], syf[WAVE];       // the same in float32, x and y apart (pairs of neighbours are read as one packed operand);
-                                      // entries beyond the swarm hold 1e30: first-stage jamming tests of the step
+    union {
+        struct {
+            float sxf[WAVE], syf[WAVE];   // the same in float32, x and y apart (pairs of neighbours are read as one packed
+                                          // operand); entries beyond the swarm hold 1e30: first-stage jamming tests of the step
+        };
+        double py[WAVE];              // previous centroids (until the float32 copies are written)
+    };
     double jx[WAVE], jy[WAVE];        // jammer positions
-    unsigned long long xfer[WAVE];    // lane-to-lane hand-over of 64-bit rows
-    double cx[WAVE + 2], cy[WAVE + 2];  // centroids in dict order
-    double px[WAVE + 2], py[WAVE + 2];  // previous centroids
-    int csz[WAVE + 2];
+    union {
+        unsigned long long xfer[WAVE];    // lane-to-lane hand-over of 64-bit rows
+        double px[WAVE];                  // previous centroids (until the complement rows are compacted)
+    };
+    double cx[WAVE], cy[WAVE];        // centroids in dict order
+    int csz[WAVE];
     int lab[WAVE];
     int asg[WAVE];
     int jb[WAVE];
@@ -1389,7 +1400,7 @@ enum { SOLVE_HIST_SUBS = 16, SOLVE_HIST_STRIDE = 80, SOLVE_HIST_TOTAL = SOLVE_HI
 // FUSED = 0: as described.  FUSED = NPAD > 0: the solve follows in the same wave (one launch per step): taken for
 // small batches and small swarms, where the extra launches cost more than the scheduling gains.
 template <int FUSED>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 ? 1 : 6, FUSED > 0 ? 4 : 8))) void env_step_front_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 ? 1 : 8, FUSED > 0 ? 4 : 8))) void env_step_front_kernel(MarlEnvParams P, MarlEnvState S, MarlStepIO io) {
     extern __shared__ __align__(16) unsigned char smem[];
     WaveLds& L = carve(smem);
     const int e = blockIdx.x, lane = threadIdx.x;
@@ -1422,6 +1433,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 
     if (io.noise) { nx = io.noise[oi * 2]; ny = io.noise[oi * 2 + 1]; }
     const int tick = S.tick[e] + 1;
     int num = S.n_clusters[e], ncent = S.ncent[e];
+    ncent = ncent < 0 ? 0 : (ncent > WAVE ? WAVE : ncent);          // never more than 64 entries (WaveLds)
     const double lam0 = S.lambda2_initial[e];
     // the cluster table is read up to its fill level only (the level arrives with the first loads; the
     // table is not needed before the enemy dynamics are done)
@@ -1461,9 +1473,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 
         if (ct) S.enemy_omega[oi] = ew;
         S.enemy_x[oi] = ex; S.enemy_y[oi] = ey; S.enemy_vx[oi] = evx; S.enemy_vy[oi] = evy;
         L.sxy[lane] = make_double2(ex, ey);
-        L.sxf[lane] = (float)ex; L.syf[lane] = (float)ey;
-    } else {
-        L.sxf[lane] = 1e30f; L.syf[lane] = 1e30f;          // squares overflow to +inf: never within range
     }
     WSYNC();
     FSTAMP(0);
@@ -1501,8 +1510,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 
             L.cy[s] = S.cent_y[(size_t)e * KS + s];
             L.csz[s] = S.cent_size[(size_t)e * KS + s];
         }
-        WSYNC();
     }
+    // float32 copies for the first stage of the jamming test (their storage held the previous centroids until here)
+    L.sxf[lane] = (lane < n) ? (float)ex : 1e30f;          // 1e30: squares overflow to +inf, never within range
+    L.syf[lane] = (lane < n) ? (float)ey : 1e30f;
+    WSYNC();
     FSTAMP(1);
     // -- lambda2 of the jammed graph (jammer_env.py:464-508)
     uint64_t adj, jam;
@@ -1737,6 +1749,7 @@ void env_reset_wave_kernel(MarlEnvParams P, MarlEnvState S, MarlResetIO io) {
     const uint32_t k0 = (uint32_t)io.seed, k1 = (uint32_t)(io.seed >> 32);
     int num = S.n_clusters[e], ncent = S.ncent[e];
     ncent = ncent < 0 ? 0 : (ncent > KS ? KS : ncent);       // an unzeroed buffer must not send the copy loops astray
+    ncent = ncent > WAVE ? WAVE : ncent;
     int eband = 2;
     double lam0 = 0.0;
     const bool host_init = io.enemy_pos != nullptr;
