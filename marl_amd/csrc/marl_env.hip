@@ -2074,14 +2074,23 @@ __global__ void fill_noise_kernel(MarlEnvParams P, MarlEnvState S, uint64_t seed
 // (column-major, lane j touches only the rows it owns, so no cross-lane visibility is
 // needed) -- correct, but memory-bound.
 template <int S>
+// Three groups of arrays are never live together and share their storage: the previous centroids (a re-clustering
+// step, before the link rows are built), the compacted complement rows (from the compaction to their hand-over: into
+// registers, or to global memory for the launches that follow) and the solver's vectors (after that).  20 KB instead
+// of 32 KB at S = 4: eight envs per compute unit instead of five.
 struct BigLds {
     static constexpr int NN = WAVE * S;
     double sx[NN], sy[NN];
     double jx[WAVE], jy[WAVE];
-    double2 de[NN];
-    __attribute__((aligned(16))) double uvec[NN], qvec[NN];
-    unsigned long long xfer[NN * S];
-    double cx[NN + 2], cy[NN + 2], px[NN + 2], py[NN + 2];
+    union {
+        struct {
+            double2 de[NN];
+            __attribute__((aligned(16))) double uvec[NN], qvec[NN];
+        };
+        unsigned long long xfer[NN * S];
+        struct { double px[NN + 2], py[NN + 2]; };
+    };
+    double cx[NN + 2], cy[NN + 2];
     int csz[NN + 2];
     int lab[NN];
     int asg[WAVE];
@@ -2476,6 +2485,7 @@ __device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int 
     WSYNC();
     if (np <= WAVE) {
         const uint64_t crow = (lane < np) ? L.xfer[lane * S] : 0ull;
+        WSYNC();                                // the solver's arrays lie where the rows were
         return (double)n - mu_max_in_wave<WAVE>(crow, np, lane, L, rounds, (double)n);
     }
     // (rows_follow: the Lanczos launch on bit rows comes next, which takes any size up to S * 64 and, should it fail
@@ -2492,6 +2502,7 @@ __device__ __forceinline__ double lambda2_big(const uint64_t (&rows)[S][S], int 
     for (int s = 0; s < S; ++s)
 #pragma unroll
         for (int q = 0; q < S; ++q) w[s][q] = (s * WAVE + lane < np) ? L.xfer[(s * WAVE + lane) * S + q] : 0ull;
+    WSYNC();                                    // the solver's arrays lie where the rows were
     return (double)n - mu_max_global_wave<S>(w, np, lane, L, rounds, As, big_ld(n));
 }
 
