@@ -61,6 +61,9 @@ extern "C" {
  * marl_lambda2_from_bits, the reset and the one-launch (fused) step take the direct solver. */
 #define MARL_LAMBDA2_DIRECT 0x100
 #define MARL_LAMBDA2_LANCZOS 0x200
+#define MARL_LAMBDA2_TEST_FEW_STEPS 0x400 /* testing, marl_lambda2_from_bits with MARL_LAMBDA2_LANCZOS at N > 64: the iteration
+                                           gives up after 24 steps, so that what follows a failure (the team solver's list,
+                                           the solve in place once that is full) can be exercised */
 #define MARL_STAGE_NO_RECLUSTER 1        /* marl_env_step leaves the K_recompute re-clustering (jammer_env.py:394-402) out:
                                            the cluster table of the last reset stays; with MarlStepIO.obs = NULL this is the
                                            "step + reward only" form of the step */

@@ -21,6 +21,7 @@ STAGE_NO_RECLUSTER = 1
 STAGE_NO_SOLVE_PRIORITY = 2
 STAGE_GENERAL_RESET = 4
 LAMBDA2_DIRECT, LAMBDA2_LANCZOS = 0x100, 0x200
+LAMBDA2_TEST_FEW_STEPS = 0x400        # testing: the bit-row Lanczos iteration gives up after 24 steps
 
 MARL_OK, MARL_EINVAL, MARL_EUNSUPPORTED, MARL_EHIP, MARL_ETOOBIG = 0, -1, -2, -3, -4
 STATIC_SCRATCH_BYTES = 32 << 20

@@ -3136,9 +3136,9 @@ constexpr size_t rows_lds_bytes() {
 // global memory (true again).
 template <int S>
 __device__ __forceinline__ bool rows_solve(double* region, int ld, int np, int lane, double nfull, unsigned char* raw, int rounds,
-                                           int e, int* team_list, double& mu) {
+                                           int kmax, int e, int* team_list, double& mu) {
     const unsigned long long* rows = reinterpret_cast<const unsigned long long*>(region);
-    if (mu_max_lanczos_rows<S>(rows, np, lane, nfull, *reinterpret_cast<LanczosRowsLds<S>*>(raw), rounds, mu)) return true;
+    if (mu_max_lanczos_rows<S>(rows, np, lane, nfull, *reinterpret_cast<LanczosRowsLds<S>*>(raw), rounds, kmax, mu)) return true;
     int at = TEAM_LIST_MAX;                  // (a problem beyond the team solver's size does not ask for a place)
     if (lane == 0 && np <= TEAM_MAX_NP) at = atomicAdd(&team_list[0], 1);
     at = __builtin_amdgcn_readfirstlane(at);
@@ -3175,7 +3175,7 @@ __global__ __launch_bounds__(WAVE) void env_step_lanczos_rows_kernel(MarlEnvPara
     if (np <= 0 || rows_pass_of(np, P.N) != (int)blockIdx.x / St.E) return;
     const int ld = big_ld(P.N);
     double mu;
-    if (!rows_solve<S>(St.workspace + (size_t)e * ld * ld, ld, np, lane, (double)P.N, raw, P.lambda2_rounds, e,
+    if (!rows_solve<S>(St.workspace + (size_t)e * ld * ld, ld, np, lane, (double)P.N, raw, P.lambda2_rounds, LANCZOS_ROWS_KMAX, e,
                        workspace_team_list(St.workspace, P.N, St.E), mu))
         return;
     if (lane == 0) {
@@ -3191,13 +3191,13 @@ __global__ __launch_bounds__(WAVE) void env_step_lanczos_rows_kernel(MarlEnvPara
 }
 template <int S>
 __global__ __launch_bounds__(WAVE) void lambda2_lanczos_rows_kernel(int n, int E, int* pend, double* ws, int ld, int* team_list,
-                                                                    double* lambda2, int rounds) {
+                                                                    double* lambda2, int rounds, int kmax) {
     __shared__ __align__(16) unsigned char raw[rows_lds_bytes<S>()];
     const int e = blockIdx.x % E, lane = threadIdx.x;
     const int np = pend[e];
     if (np <= 0 || rows_pass_of(np, n) != (int)blockIdx.x / E) return;
     double mu;
-    if (!rows_solve<S>(ws + (size_t)e * ld * ld, ld, np, lane, (double)n, raw, rounds, e, team_list, mu)) return;
+    if (!rows_solve<S>(ws + (size_t)e * ld * ld, ld, np, lane, (double)n, raw, rounds, kmax, e, team_list, mu)) return;
     if (lane == 0) {
         lambda2[e] = (double)n - mu;
         pend[e] = 0;
@@ -3351,7 +3351,7 @@ int static_scratch(void** out) {
 // A `rounds` value: multisection rounds in the low byte (0 = the default, 8) plus at most one solver selector.
 int check_rounds(int32_t* rounds) {
     const int32_t sel = *rounds & (MARL_LAMBDA2_DIRECT | MARL_LAMBDA2_LANCZOS);
-    if (*rounds < 0 || (*rounds & ~(0xFF | MARL_LAMBDA2_DIRECT | MARL_LAMBDA2_LANCZOS)) ||
+    if (*rounds < 0 || (*rounds & ~(0xFF | MARL_LAMBDA2_DIRECT | MARL_LAMBDA2_LANCZOS | MARL_LAMBDA2_TEST_FEW_STEPS)) ||
         sel == (MARL_LAMBDA2_DIRECT | MARL_LAMBDA2_LANCZOS))
         return MARL_EINVAL;
     if ((*rounds & 0xFF) == 0) *rounds |= 8;
@@ -3832,6 +3832,7 @@ int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t* bits, double* l
     }
     if (check_rounds(&rounds) != MARL_OK) return MARL_EINVAL;
     const bool lanczos = (rounds & MARL_LAMBDA2_LANCZOS) != 0;       // the stage op takes the direct solver unless asked
+    const bool few_steps = (rounds & MARL_LAMBDA2_TEST_FEW_STEPS) != 0;
     rounds &= 0xFF;
     if (N > WAVE) {
         if (workspace == nullptr) return MARL_EINVAL;
@@ -3842,7 +3843,7 @@ int marl_lambda2_from_bits(int32_t N, int32_t E, const uint32_t* bits, double* l
         if (lanczos) {
             int* team_list = workspace_team_list((double*)workspace, N, E);
             MARL_DISPATCH_ROWS(N, lambda2_lanczos_rows_kernel, dim3(E * ROWS_PASSES), stream, (int)N, (int)E, pend, (double*)workspace, (int)ld, team_list,
-                               lambda2, (int)rounds);
+                               lambda2, (int)rounds, few_steps ? 24 : LANCZOS_ROWS_KMAX);
             MARL_LAUNCH_TEAM(N, lambda2_team_kernel, (E < TEAM_LIST_MAX ? E : TEAM_LIST_MAX), stream, (int)N, (const int*)pend,
                              (const double*)workspace, ld * ld, lambda2, (int)rounds, (const int*)team_list);
         } else {

@@ -90,7 +90,8 @@ def test_lanczos_on_bit_rows_against_lapack(n):
 def test_lanczos_failures_beyond_the_team_list_are_solved_in_place():
     """What the iteration does not settle goes on a list of 1 024 envs for the team solver; a failure that finds the list
     full is solved by its own wave through global memory.  1 200 copies of a graph whose complement is a path (the top
-    of its spectrum, 2 - 2 cos(k pi / n), is a cluster with gaps of 1e-3: hundreds of steps) fill the list and overflow it."""
+    of its spectrum, 2 - 2 cos(k pi / n), is a cluster with gaps of 1e-3), with the iteration limited to 24 steps
+    (MARL_LAMBDA2_TEST_FEW_STEPS), fill the list and overflow it."""
     n, E = 130, 1200
     comp = np.zeros((n, n), dtype=bool)
     i = np.arange(n - 1)
@@ -104,8 +105,8 @@ def test_lanczos_failures_beyond_the_team_list_are_solved_in_place():
     nb = lib.marl_lambda2_workspace_bytes(n, E)
     ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")
     out = torch.zeros(E, dtype=torch.float64, device="cuda")
-    _lib.check(lib.marl_lambda2_from_bits(n, E, bits.data_ptr(), out.data_ptr(), _lib.LAMBDA2_LANCZOS, ws.data_ptr(),
-                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    _lib.check(lib.marl_lambda2_from_bits(n, E, bits.data_ptr(), out.data_ptr(), _lib.LAMBDA2_LANCZOS | _lib.LAMBDA2_TEST_FEW_STEPS,
+                                          ws.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     ld = (n + 7) // 8 * 8
     listed = int(ws[E * ld * ld * 8 + (E + 63) // 64 * 64 * 4:][:4].view(torch.int32)[0])
