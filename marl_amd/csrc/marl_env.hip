@@ -2265,6 +2265,130 @@ __device__ __forceinline__ void pair_rows_big_fused(uint64_t (&adj)[S][S], uint6
     }
 }
 
+// The float32 first stage of the jamming test (jam_pass_f32: two thresholds around the exact one, packed pipe, sign
+// bits) for rows of more than 64 columns: `cnt` (even, 2 .. 32) columns from j0 on, against KJ jammers.
+template <int KJ>
+__device__ __forceinline__ void jam_word_f32(const float* sxf, const float* syf, float xi, float yi, int j0, int cnt,
+                                             float tl, float th, const float (&q2x)[4], const float (&q2y)[4],
+                                             uint32_t& sb, uint32_t& mb) {
+    const v2f xi2 = {xi, xi}, yi2 = {yi, yi}, tl2 = {tl, tl}, th2 = {th, th};
+    uint32_t sw = 0, mw = 0;
+    for (int j = j0; j < j0 + cnt; j += 2) {
+        const v2f xj = *reinterpret_cast<const v2f*>(&sxf[j]), yj = *reinterpret_cast<const v2f*>(&syf[j]);
+        const v2f sx = xi2 + xj, sy = yi2 + yj;
+        v2f dmin = {0.0f, 0.0f};
+        static_for<0, KJ>([&](auto k) {
+            const v2f qx = {q2x[decltype(k)::value], q2x[decltype(k)::value]};
+            const v2f qy = {q2y[decltype(k)::value], q2y[decltype(k)::value]};
+            const v2f DX = qx - sx, DY = qy - sy;
+            const v2f d2 = __builtin_elementwise_fma(DX, DX, DY * DY);
+            if constexpr (decltype(k)::value == 0) dmin = d2;
+            else dmin = v2f{fminf(dmin.x, d2.x), fminf(dmin.y, d2.y)};
+        });
+        const v2f a = dmin - tl2, b = dmin - th2;
+        sw = __builtin_amdgcn_alignbit(sw, __float_as_uint(a.x), 31);
+        sw = __builtin_amdgcn_alignbit(sw, __float_as_uint(a.y), 31);
+        mw = __builtin_amdgcn_alignbit(mw, __float_as_uint(b.x), 31);
+        mw = __builtin_amdgcn_alignbit(mw, __float_as_uint(b.y), 31);
+    }
+    sb |= __brev(sw) >> (32 - cnt);
+    mb |= __brev(mw) >> (32 - cnt);
+}
+
+// Jamming rows of a step whose adjacency is the complete graph (communication range beyond the arena's diagonal): the
+// float32 stage over every (row, column pair, matching jammer), then the exact float64 expression of pair_chunk_big
+// for the pairs that fell between its two thresholds, which therefore still decides every bit.  The float32 copies of
+// the positions lie in L.xfer, which nothing uses between the re-clustering and the compaction of the rows.
+template <int S>
+__device__ __forceinline__ void jam_rows_big_f32(uint64_t (&adj)[S][S], uint64_t (&jam)[S][S], BigLds<S>& L, int n, int m,
+                                                 int lane, int eband, double d2_jam, float thr_lo, float thr_hi) {
+    constexpr int NN = WAVE * S;
+    float* sxf = reinterpret_cast<float*>(L.xfer);
+    float* syf = sxf + NN;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = s * WAVE + lane;
+        sxf[i] = (i < n) ? (float)L.sx[i] : 1e30f;          // 1e30: squares overflow to +inf, never within range
+        syf[i] = (i < n) ? (float)L.sy[i] : 1e30f;
+    }
+    WSYNC();
+    const uint64_t matching = ballot64(lane < m && L.jb[lane] == eband);
+    uint64_t sure[S][S], maybe[S][S];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int k = 0; k < S; ++k) { sure[s][k] = 0; maybe[s][k] = 0; }
+    const float tl = nextafterf(thr_lo, INFINITY), th = nextafterf(thr_hi, INFINITY);
+    uint64_t mm = (d2_jam < 0.0) ? 0ull : matching;
+    while (mm) {
+        float q2x[4], q2y[4];
+        int kj = 0;
+        static_for<0, 4>([&](auto k) {
+            float x = 1e30f, y = 1e30f;
+            if (mm) {
+                const int j = __ffsll((unsigned long long)mm) - 1;
+                mm &= mm - 1;
+                x = (float)(2.0 * L.jx[j]); y = (float)(2.0 * L.jy[j]);
+                ++kj;
+            }
+            q2x[decltype(k)::value] = x; q2y[decltype(k)::value] = y;
+        });
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int i = s * WAVE + lane;
+            const float xi = sxf[i], yi = syf[i];
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                const int left = n - k * WAVE;               // columns of this word: wave-uniform
+                if (left <= 0) continue;
+                uint32_t s_lo = 0, s_hi = 0, m_lo = 0, m_hi = 0;
+                const int c_lo = left < 32 ? ((left + 1) & ~1) : 32;
+                const int c_hi = left > 32 ? (left < 64 ? ((left - 32 + 1) & ~1) : 32) : 0;
+                switch (kj) {
+                    case 1: jam_word_f32<1>(sxf, syf, xi, yi, k * WAVE, c_lo, tl, th, q2x, q2y, s_lo, m_lo);
+                            if (c_hi) jam_word_f32<1>(sxf, syf, xi, yi, k * WAVE + 32, c_hi, tl, th, q2x, q2y, s_hi, m_hi); break;
+                    case 2: jam_word_f32<2>(sxf, syf, xi, yi, k * WAVE, c_lo, tl, th, q2x, q2y, s_lo, m_lo);
+                            if (c_hi) jam_word_f32<2>(sxf, syf, xi, yi, k * WAVE + 32, c_hi, tl, th, q2x, q2y, s_hi, m_hi); break;
+                    case 3: jam_word_f32<3>(sxf, syf, xi, yi, k * WAVE, c_lo, tl, th, q2x, q2y, s_lo, m_lo);
+                            if (c_hi) jam_word_f32<3>(sxf, syf, xi, yi, k * WAVE + 32, c_hi, tl, th, q2x, q2y, s_hi, m_hi); break;
+                    default: jam_word_f32<4>(sxf, syf, xi, yi, k * WAVE, c_lo, tl, th, q2x, q2y, s_lo, m_lo);
+                            if (c_hi) jam_word_f32<4>(sxf, syf, xi, yi, k * WAVE + 32, c_hi, tl, th, q2x, q2y, s_hi, m_hi); break;
+                }
+                sure[s][k] |= ((uint64_t)s_hi << 32) | s_lo;
+                maybe[s][k] |= ((uint64_t)m_hi << 32) | m_lo;
+            }
+        }
+    }
+    const double thr4 = 4.0 * d2_jam;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = s * WAVE + lane;
+        const double xi = L.sx[i < n ? i : 0], yi = L.sy[i < n ? i : 0];
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            uint64_t keep = (i < n) ? word_mask<S>(n, k) : 0ull;
+            if (k == s) keep &= ~(1ull << lane);
+            adj[s][k] = keep;
+            uint64_t jw = sure[s][k] & keep;
+            uint64_t open = maybe[s][k] & ~sure[s][k] & keep;
+            while (open) {                      // rare: a band of a few parts per million around the radius
+                const int b = __ffsll((unsigned long long)open) - 1;
+                open &= open - 1;
+                const double sx = xi + L.sx[k * WAVE + b], sy = yi + L.sy[k * WAVE + b];
+                bool hit = false;
+                for (uint64_t mk = matching; mk; mk &= mk - 1) {
+                    const int q = __ffsll((unsigned long long)mk) - 1;
+                    const double DX = 2.0 * L.jx[q] - sx, DY = 2.0 * L.jy[q] - sy;
+                    hit |= (DX * DX + DY * DY <= thr4);
+                }
+                if (hit) jw |= 1ull << b;
+            }
+            jam[s][k] = jw;
+        }
+    }
+    WSYNC();                                    // L.xfer is free again
+}
+
 template <int S>
 __device__ __forceinline__ void store_bits_big(uint32_t* dst, int e, int n, int lane, const uint64_t (&rows)[S][S]) {
     if (dst == nullptr) return;
@@ -2706,7 +2830,10 @@ __global__ __launch_bounds__(WAVE) void env_step_big_kernel(MarlEnvParams P, Mar
         WSYNC();
     }
     uint64_t adj[S][S], jam[S][S];
-    pair_rows_big_fused<S>(adj, jam, L, n, m, lane, eband, P.comm_d2_max[eband], P.jam_d2_max[eband], arena);
+    if (arena > 0.0 && P.comm_d2_max[eband] >= 2.000001 * arena * arena)
+        jam_rows_big_f32<S>(adj, jam, L, n, m, lane, eband, P.jam_d2_max[eband], P.jam_lo_f32[eband], P.jam_hi_f32[eband]);
+    else
+        pair_rows_big_fused<S>(adj, jam, L, n, m, lane, eband, P.comm_d2_max[eband], P.jam_d2_max[eband], arena);
     store_bits_big<S>(io.adj_bits, e, n, lane, adj);
     store_bits_big<S>(io.jam_bits, e, n, lane, jam);
 #pragma unroll

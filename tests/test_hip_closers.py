@@ -276,16 +276,19 @@ def test_parts_need_the_wave_kernels():
 
 
 # ---------------------------------------------------------------- float32 first stage of the step's jamming test
-@pytest.mark.parametrize("arena,band", [(200.0, 0), (200.0, 3), (6000.0, 2)])
-def test_step_jamming_mask_is_exact_around_the_float32_guard_band(arena, band):
+@pytest.mark.parametrize("arena,band,extra", [(200.0, 0, 0), (200.0, 3, 0), (6000.0, 2, 0), (200.0, 0, 58), (200.0, 1, 158),
+                                              (200.0, 2, 214)])
+def test_step_jamming_mask_is_exact_around_the_float32_guard_band(arena, band, extra):
     """The step evaluates the jamming test in float32 first and settles the pairs inside a guard band around
     the radius with the exact float64 expression.  Link midpoints are planted at R (1 + eps) from a jammer for
     eps from one ulp to 1e-4 on both sides (inside the band, at its edges and outside), with the enemies held
-    still (v_enemy = 0) so that the planted geometry is what the step sees: bits equal the reference expression."""
+    still (v_enemy = 0) so that the planted geometry is what the step sees: bits equal the reference expression.
+    `extra` further enemies at random places bring the swarm to 100, 200 and 256: the kernels for more than 64 enemies
+    have a first stage of their own."""
     rng = np.random.RandomState(5)
     eps_list = [0.0, 1.2e-16, -1.2e-16, 1e-12, -1e-12, 1e-9, -1e-9, 1e-7, -1e-7, 5e-7, -5e-7, 1e-6, -1e-6, 2e-6, -2e-6,
                 4e-6, -4e-6, 1e-5, -1e-5, 1e-4, -1e-4]
-    N, M, E = 2 * len(eps_list), 2, 8
+    N, M, E = 2 * len(eps_list) + extra, 2, 8
     p = orc.EnvParams(M=M, N=N, arena_size=arena, P_jammer_dbm=20.0 if arena < 1000 else 30.0,
                       P_jam_thresh_dbm=-40.0 if arena < 1000 else -45.0, v_enemy=0.0, random_jammer_start=True)
     R = orc.compute_jam_range(orc.db_to_watts(p.P_jammer_dbm), orc.db_to_watts(p.P_jam_thresh_dbm),
@@ -302,6 +305,7 @@ def test_step_jamming_mask_is_exact_around_the_float32_guard_band(arena, band):
             mid = q + R * (1.0 + eps) * np.array([np.cos(ang), np.sin(ang)])
             d = half * np.array([-np.sin(ang), np.cos(ang)])
             epos[e, 2 * t], epos[e, 2 * t + 1] = mid + d, mid - d
+        epos[e, 2 * len(eps_list):] = rng.uniform(0.0, arena, size=(extra, 2))
         epos[e] = np.clip(epos[e], 0.0, arena)
     jb = np.tile(np.array([band, (band + 1) % 4], np.int32), (E, 1))
     env.reset(enemy_pos=epos, enemy_vel=np.tile(np.array([1.0, 0.0]), (E, N, 1)),
