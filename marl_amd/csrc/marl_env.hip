@@ -3258,21 +3258,31 @@ template <int S>
 constexpr size_t rows_lds_bytes() {
     return sizeof(LanczosRowsLds<S>) > sizeof(GlobalSolveLds<S>) ? sizeof(LanczosRowsLds<S>) : sizeof(GlobalSolveLds<S>);
 }
-// The Lanczos iteration on env e's pending eigenproblem.  True: mu holds mu_max.  False: not within its bound, and the
-// env is on the team solver's list now -- unless that was full, in which case the wave has solved it by itself through
-// global memory (true again).
-template <int S>
-__device__ __forceinline__ bool rows_solve(double* region, int ld, int np, int lane, double nfull, unsigned char* raw, int rounds,
+// The Lanczos iteration on env e's pending eigenproblem, by the W waves of the workgroup.  True: mu holds mu_max.
+// False: not within its bound, and the env is on the team solver's list now -- unless that was full, in which case
+// the first wave has solved it by itself through global memory (true for that wave, the others leave).
+template <int S, int W>
+__device__ __forceinline__ bool rows_solve(double* region, int ld, int np, int tid, double nfull, unsigned char* raw, int rounds,
                                            int kmax, int e, int* team_list, double& mu) {
     const unsigned long long* rows = reinterpret_cast<const unsigned long long*>(region);
-    if (mu_max_lanczos_rows<S>(rows, np, lane, nfull, *reinterpret_cast<LanczosRowsLds<S>*>(raw), rounds, kmax, mu)) return true;
+    LanczosRowsLds<S>& L = *reinterpret_cast<LanczosRowsLds<S>*>(raw);
+    if (mu_max_lanczos_rows<S, W>(rows, np, tid, nfull, L, rounds, kmax, mu)) return true;
+    const int lane = tid & (WAVE - 1);
     int at = TEAM_LIST_MAX;                  // (a problem beyond the team solver's size does not ask for a place)
-    if (lane == 0 && np <= TEAM_MAX_NP) at = atomicAdd(&team_list[0], 1);
-    at = __builtin_amdgcn_readfirstlane(at);
+    if (tid == 0 && np <= TEAM_MAX_NP) at = atomicAdd(&team_list[0], 1);
+    if constexpr (W == 1) {
+        at = __builtin_amdgcn_readfirstlane(at);
+    } else {
+        WSYNC();
+        if (tid == 0) L.red[0][0] = (double)at;
+        WSYNC();
+        at = (int)L.red[0][0];
+    }
     if (at < TEAM_LIST_MAX && np <= TEAM_MAX_NP) {
-        if (lane == 0) team_list[1 + at] = e;
+        if (tid == 0) team_list[1 + at] = e;
         return false;
     }
+    if (tid >= WAVE) return false;           // the solve in place is one wave's
     uint64_t w[S][S];                        // the rows lie where the matrix goes: into registers first
 #pragma unroll
     for (int s = 0; s < S; ++s)
@@ -3284,8 +3294,8 @@ __device__ __forceinline__ bool rows_solve(double* region, int ld, int np, int l
 }
 
 // Between the two launches of a step for 64 < N <= 256 (and of the stage op): the Lanczos iteration on the pending
-// eigenproblems, one wave each, straight from the compacted bit rows.  A problem that meets its bound is finished here
-// (pending count cleared); the others go on the list that the team launch works through.
+// eigenproblems, straight from the compacted bit rows, W waves per problem.  A problem that meets its bound is finished
+// here (pending count cleared); the others go on the list that the team launch works through.
 //
 // The launch is as long as its slowest solve started late, and the slow ones are the large ones (more vertices, more
 // steps).  The grid therefore passes over the envs ROWS_PASSES times -- workgroup b looks at env b mod E and takes it
@@ -3293,19 +3303,19 @@ __device__ __forceinline__ bool rows_solve(double* region, int ld, int np, int l
 // one starts; a workgroup that only looks costs a few nanoseconds.
 constexpr int ROWS_PASSES = 3;
 __device__ __forceinline__ int rows_pass_of(int np, int n) { return 4 * np >= 3 * n ? 0 : (2 * np >= n ? 1 : 2); }
-template <int S>
-__global__ __launch_bounds__(WAVE) void env_step_lanczos_rows_kernel(MarlEnvParams P, MarlEnvState St, MarlStepIO io) {
+template <int S, int W>
+__global__ __launch_bounds__(WAVE * W) void env_step_lanczos_rows_kernel(MarlEnvParams P, MarlEnvState St, MarlStepIO io) {
     __shared__ __align__(16) unsigned char raw[rows_lds_bytes<S>()];
-    const int e = blockIdx.x % St.E, lane = threadIdx.x;
+    const int e = blockIdx.x % St.E, tid = threadIdx.x;
     int* pend = workspace_pending(St.workspace, P.N, St.E);
     const int np = pend[e];
     if (np <= 0 || rows_pass_of(np, P.N) != (int)blockIdx.x / St.E) return;
     const int ld = big_ld(P.N);
     double mu;
-    if (!rows_solve<S>(St.workspace + (size_t)e * ld * ld, ld, np, lane, (double)P.N, raw, P.lambda2_rounds, LANCZOS_ROWS_KMAX, e,
-                       workspace_team_list(St.workspace, P.N, St.E), mu))
+    if (!rows_solve<S, W>(St.workspace + (size_t)e * ld * ld, ld, np, tid, (double)P.N, raw, P.lambda2_rounds, LANCZOS_ROWS_KMAX, e,
+                          workspace_team_list(St.workspace, P.N, St.E), mu))
         return;
-    if (lane == 0) {
+    if (tid == 0) {
         const double lam = (double)P.N - mu;
         const double* part = St.solve_partial + (size_t)e * 4;
         double r1;
@@ -3316,16 +3326,16 @@ __global__ __launch_bounds__(WAVE) void env_step_lanczos_rows_kernel(MarlEnvPara
         pend[e] = 0;
     }
 }
-template <int S>
-__global__ __launch_bounds__(WAVE) void lambda2_lanczos_rows_kernel(int n, int E, int* pend, double* ws, int ld, int* team_list,
-                                                                    double* lambda2, int rounds, int kmax) {
+template <int S, int W>
+__global__ __launch_bounds__(WAVE * W) void lambda2_lanczos_rows_kernel(int n, int E, int* pend, double* ws, int ld, int* team_list,
+                                                                        double* lambda2, int rounds, int kmax) {
     __shared__ __align__(16) unsigned char raw[rows_lds_bytes<S>()];
-    const int e = blockIdx.x % E, lane = threadIdx.x;
+    const int e = blockIdx.x % E, tid = threadIdx.x;
     const int np = pend[e];
     if (np <= 0 || rows_pass_of(np, n) != (int)blockIdx.x / E) return;
     double mu;
-    if (!rows_solve<S>(ws + (size_t)e * ld * ld, ld, np, lane, (double)n, raw, rounds, kmax, e, team_list, mu)) return;
-    if (lane == 0) {
+    if (!rows_solve<S, W>(ws + (size_t)e * ld * ld, ld, np, tid, (double)n, raw, rounds, kmax, e, team_list, mu)) return;
+    if (tid == 0) {
         lambda2[e] = (double)n - mu;
         pend[e] = 0;
     }
@@ -3524,11 +3534,16 @@ size_t workspace_bytes(int N, int E) {
         default: hipLaunchKernelGGL((kern<4>), grid, dim3(WAVE), sizeof(BigLds<4>), (hipStream_t)(stream), __VA_ARGS__); break; \
     }
 // the same for kernels whose LDS is static (the Lanczos iteration on bit rows)
+#ifndef ROWS_WAVES_4
+#define ROWS_WAVES_2 1      /* waves per graph in the rows launch, by row slots (see mu_max_lanczos_rows) */
+#define ROWS_WAVES_3 1
+#define ROWS_WAVES_4 2
+#endif
 #define MARL_DISPATCH_ROWS(N, kern, grid, stream, ...)                                                             \
     switch (((N) + WAVE - 1) / WAVE) {                                                                             \
-        case 2: hipLaunchKernelGGL((kern<2>), grid, dim3(WAVE), 0, (hipStream_t)(stream), __VA_ARGS__); break;     \
-        case 3: hipLaunchKernelGGL((kern<3>), grid, dim3(WAVE), 0, (hipStream_t)(stream), __VA_ARGS__); break;     \
-        default: hipLaunchKernelGGL((kern<4>), grid, dim3(WAVE), 0, (hipStream_t)(stream), __VA_ARGS__); break;    \
+        case 2: hipLaunchKernelGGL((kern<2, ROWS_WAVES_2>), grid, dim3(WAVE * ROWS_WAVES_2), 0, (hipStream_t)(stream), __VA_ARGS__); break;  \
+        case 3: hipLaunchKernelGGL((kern<3, ROWS_WAVES_3>), grid, dim3(WAVE * ROWS_WAVES_3), 0, (hipStream_t)(stream), __VA_ARGS__); break;  \
+        default: hipLaunchKernelGGL((kern<4, ROWS_WAVES_4>), grid, dim3(WAVE * ROWS_WAVES_4), 0, (hipStream_t)(stream), __VA_ARGS__); break; \
     }
 #endif
 
