@@ -3537,7 +3537,7 @@ size_t workspace_bytes(int N, int E) {
 #ifndef ROWS_WAVES_4
 #define ROWS_WAVES_2 1      /* waves per graph in the rows launch, by row slots (see mu_max_lanczos_rows) */
 #define ROWS_WAVES_3 1
-#define ROWS_WAVES_4 2
+#define ROWS_WAVES_4 1
 #endif
 #define MARL_DISPATCH_ROWS(N, kern, grid, stream, ...)                                                             \
     switch (((N) + WAVE - 1) / WAVE) {                                                                             \
