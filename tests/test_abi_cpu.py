@@ -105,6 +105,12 @@ def test_argument_validation_without_launch():
     io = _lib.MarlStepIO()
     assert lib.marl_env_step(C.byref(p), C.byref(st), C.byref(io), None) == _lib.MARL_EINVAL
     assert lib.marl_env_step(None, None, None, None) == _lib.MARL_EINVAL
+    assert lib.marl_env_step_timed(C.byref(p), C.byref(st), C.byref(io), None, None, None) == _lib.MARL_EINVAL   # no events
+    assert lib.marl_reward_obs(C.byref(p), 4, None, None) == _lib.MARL_EINVAL
+    # a `rounds` word: rounds in the low byte, at most one solver selector, nothing unknown
+    for bad in (-1, _lib.LAMBDA2_DIRECT | _lib.LAMBDA2_LANCZOS, 0x800, 0x10000):
+        assert lib.marl_lambda2_from_bits(10, 1, C.cast(1 << 12, _lib._pu32), C.cast(1 << 12, _lib._pd), bad, None, None) \
+            == _lib.MARL_EINVAL, hex(bad)
     assert lib.marl_lambda2_from_bits(0, 1, None, None, 0, None, None) == _lib.MARL_EINVAL
     assert lib.marl_gae(0, 1, None, None, None, None, None, 0.99, 0.95, None, None, None) == _lib.MARL_EINVAL
     assert b"invalid" in lib.marl_strerror(_lib.MARL_EINVAL)
