@@ -106,6 +106,25 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert abs(d["value"] - 2 * 512 * 20 / (d["ms_per_step"] * 20e-3)) / d["value"] < 1e-6
 
 
+@pytest.mark.gpu
+def test_bench_barrier_and_timing_exchange_over_rccl():
+    """The barrier and the exchange of the ranks' times as a multi-GPU run issues them -- backend nccl (RCCL), device
+    tensors -- in a group of one rank, which is what one GPU can hold."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["MASTER_PORT"] = "29741"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+           "--envs-per-gpu", "512", "--force-dist", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and len(d["per_rank_ms_per_step"]) == 1
+    assert d["per_rank_ms_per_step"][0] == pytest.approx(d["ms_per_step"])
+
+
 def test_auto_reset_launch_is_skipped_only_when_nothing_can_be_done():
     """The masked auto-reset launch is left out while no step counter can have reached max_steps (host-side
     bounds).  An env that keeps the bounds and one that always launches must stay identical, also after
