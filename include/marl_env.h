@@ -141,7 +141,11 @@ typedef struct MarlEnvState {
      * through them in that order (longest job first keeps the CUs evenly loaded) and finishes the reward.
      * A reset of every env (mask NULL) clears solve_hist; a step leaves it zero again. */
     uint64_t *solve_rows;      /* [E][64] complement adjacency row per compacted vertex */
-    int32_t *solve_np;         /* [E] vertices in the eigenproblem, 0 = lambda2 already final */
+    uint16_t *solve_meta;      /* [E][64] where twin vertices of the complement were merged (same neighbours: they only
+                                  contribute eigenvalues that cannot be the largest): multiplicity | diagonal entry << 8
+                                  of every vertex of the quotient, whose rows solve_rows then holds */
+    int32_t *solve_np;         /* [E] vertices in the eigenproblem, 0 = lambda2 already final; above bit 7, for a
+                                  quotient: n' | largest degree << 8 of the complement before merging */
     int32_t *solve_slot;       /* [E] rank of the env among those with the same solve_np */
     int32_t *solve_perm;       /* [E] env indices, largest eigenproblem first */
     int32_t *solve_hist;       /* [1344] 16 histograms of solve_np (80 words apart, envs spread by index to keep the

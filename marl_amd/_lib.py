@@ -52,7 +52,7 @@ _STATE_ARRAYS = [
     "enemy_x", "enemy_y", "enemy_vx", "enemy_vy", "enemy_omega", "jam_x", "jam_y", "jam_band", "last_vx", "last_vy",
     "step_count", "enemy_band", "tick", "lambda2_initial", "labels", "cent_x", "cent_y", "cent_size",
     "n_clusters", "ncent", "prev_x", "prev_y", "prev_n_clusters", "prev_ncent", "assign", "workspace",
-    "solve_rows", "solve_np", "solve_slot", "solve_perm", "solve_hist", "solve_partial", "episode_return",
+    "solve_rows", "solve_meta", "solve_np", "solve_slot", "solve_perm", "solve_hist", "solve_partial", "episode_return",
 ]
 
 

@@ -239,6 +239,7 @@ struct WaveLds {
     union {
         unsigned long long xfer[WAVE];    // lane-to-lane hand-over of 64-bit rows
         double px[WAVE];                  // previous centroids (until the complement rows are compacted)
+        double scale[WAVE];               // column scales of a quotient by twin classes (the eigen-solver, after the hand-over)
     };
     double cx[WAVE], cy[WAVE];        // centroids in dict order
     int csz[WAVE];
@@ -737,6 +738,37 @@ __device__ __forceinline__ double sturm_largest_wave(const LDS& L, int np, int l
 #else
 #define TSTAMP(k, pin)
 #endif
+// An eigenproblem whose twin vertices have been merged (merge_twins): per lane (vertex of the quotient) `meta` =
+// multiplicity | diagonal entry << 8; per problem `brk` = n' | dmax << 8 of the graph before merging, which bracket the
+// eigenvalue (0: nothing was merged, the matrix is the plain Laplacian of the bit rows).
+struct TwinInfo {
+    int meta = 0, brk = 0;
+};
+
+// Row `lane` of the quotient of a Laplacian by its twin classes: a[c] = -s s_c where bit c of the row is set, s the
+// square root of the lane's multiplicity and s_c the one of column c's vertex (sc[c], in LDS), `diag` on the diagonal.
+// PAIR: two problems of at most 32 vertices in the two halves of the wave (sc points at the half's part).
+template <int NPAD, bool PAIR = false>
+__device__ __forceinline__ void quotient_row_registers(uint64_t crow, int diag, double s, const double* sc, double (&a)[NPAD]) {
+    const double dg = (double)diag;
+    double ns = -s;
+    asm volatile("" : "+v"(ns) :: "memory");       // (a second build of the row starts from scratch, as in the builder below)
+    const int dg_hi = __double2hiint(dg), dg_lo = __double2loint(dg);
+    const uint32_t w_lo = (uint32_t)crow, w_hi = (uint32_t)(crow >> 32);
+    static_for<0, NPAD>([&](auto k) {
+        constexpr int c = decltype(k)::value;
+        // (four columns' scales in flight at a time: all of them at once are a second matrix of registers)
+        if constexpr (c % 4 == 0) asm volatile("" ::: "memory");
+        const double v = ns * sc[c];
+        const int on = __builtin_amdgcn_sbfe((int)(c < 32 ? w_lo : w_hi), c & 31, 1);       // 0 or -1
+        int hi = __double2hiint(v) & on, lo = __double2loint(v) & on;
+        const uint64_t dmask = PAIR ? (1ull << c) | (1ull << (c + 32)) : 1ull << c;
+        asm volatile("v_cndmask_b32_e64 %0, %0, %2, %4\n\tv_cndmask_b32_e64 %1, %1, %3, %4"
+                     : "+v"(hi), "+v"(lo) : "v"(dg_hi), "v"(dg_lo), "s"(dmask));
+        a[c] = __hiloint2double(hi, lo);
+    });
+}
+
 // Row `lane` of the Laplacian of the graph whose adjacency row is `crow`, as NPAD registers: a[c] = -1 where bit c of
 // the row is set, the degree on the diagonal (c == lane: the select mask is the constant 1 << c, spelled out because
 // the compiler would build it with a compare per column).  PINNED: the statements are volatile, so that two builds of
@@ -768,8 +800,10 @@ __device__ __forceinline__ void laplacian_row_registers(uint64_t crow, int cdeg,
 // `rounds`: multisection rounds of the eigenvalue search.  LANCZOS: problems of at least LANCZOS_MIN_NP vertices go
 // through the Lanczos iteration first (the direct solver below takes over if it does not meet its bound).
 // nfull: vertices of the whole graph (lambda2 = nfull - mu_max scales the Lanczos tolerance).
+// tw: the problem is a quotient by twin classes (sc: 64 doubles of LDS for the column scales).
 template <int NPAD, class LDS, bool PRIO = false, bool LANCZOS = false>
-__device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int lane, LDS& L, int rounds, double nfull) {
+__device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int lane, LDS& L, int rounds, double nfull,
+                                                      TwinInfo tw = TwinInfo(), double* sc = nullptr) {
     const int cdeg = __popcll(crow);
     int dmax = cdeg;
     dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, 0x128, 0xF, 0xF, false));      // row_ror:8, 4, 2, 1
@@ -780,6 +814,19 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
                max(__builtin_amdgcn_readlane(dmax, 32), __builtin_amdgcn_readlane(dmax, 48)));
 
     constexpr int KB = (NPAD + 15) / 16;
+    // a quotient: the bracket is the one of the graph before merging, the matrix has weights
+    const int brk = __builtin_amdgcn_readfirstlane(tw.brk);
+    int npb = np, diag = cdeg;
+    double s = 1.0;
+    if (brk) {
+        dmax = brk >> 8;
+        npb = brk & 0xFF;
+        diag = tw.meta >> 8;
+        s = sqrt((double)(tw.meta & 0xFF));
+        WSYNC();
+        sc[lane] = s;
+        WSYNC();
+    }
     SolvePriority<PRIO> prio;
     if constexpr (LANCZOS) {
         if (np >= LANCZOS_MIN_NP) {
@@ -787,9 +834,9 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
             double mu;
             // (the iteration works on a register matrix of its own, built a second time below if the direct solver has to
             // take over, which is rare: one set of registers live through both solvers costs the kernel a wave per SIMD)
-            if (mu_max_lanczos_wave<NPAD, LDS, PRIO>(crow, cdeg, np, lane, dmax, nfull, L, rounds, prio, mu)) {
+            if (mu_max_lanczos_wave<NPAD, LDS, PRIO>(crow, diag, np, lane, dmax, npb, brk ? sc : nullptr, s, nfull, L, rounds, prio, mu)) {
                 prio.finish();
-                return mu;
+                return brk ? fmax(mu, (double)(dmax + 1)) : mu;
             }
 #ifdef MARL_EXP_LANCZOS_STATS
             return nfull - 10000.0;
@@ -800,7 +847,9 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
         prio.start(SolvePriority<PRIO>::work(np, rounds), SolvePriority<PRIO>::work(NPAD, rounds));
     }
     double a[NPAD];                                   // row `lane` of the matrix
-    laplacian_row_registers<NPAD, LANCZOS>(crow, cdeg, a);
+    // (pinned: statements that may be hoisted out of the branch would keep both builds in registers at once)
+    if (brk) quotient_row_registers<NPAD>(crow, diag, s, sc, a);
+    else laplacian_row_registers<NPAD, true>(crow, cdeg, a);
 
 #ifdef MARL_EXP_TIMING
     double tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -808,7 +857,8 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
     asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
 #endif
     // pivot column A[lane][i]: the first one from the bits, the later ones handed back by the update
-    double col = (lane == np - 1) ? (double)cdeg : -(double)((crow >> (np - 1)) & 1ull);
+    double col = (lane == np - 1) ? (double)diag : -(double)((crow >> (np - 1)) & 1ull);
+    if (brk && lane != np - 1) col *= s * sc[np - 1];
     for (int i = np - 1; i >= 2; --i) {
         const int l = i - 1;
         prio.spend(85 + 3 * i);
@@ -859,11 +909,13 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
         if (lane == 0) { L.de[1] = make_double2(a11, a10 * a10); L.de[0] = make_double2(a00, 0.0); }
     }
     WSYNC();
+    // (a quotient whose eigenvalues all lie below dmax + 1 -- the largest one of the graph then belongs to a twin class and
+    // equals dmax + 1 -- sends the search to the bracket's lower end, which is that value)
     const double lo = (double)(dmax + 1) * (1.0 - 1e-13) - 1e-13;
-    const double hi = (double)min(np, 2 * dmax) * (1.0 + 1e-13) + 1e-13;
+    const double hi = (double)min(npb, 2 * dmax) * (1.0 + 1e-13) + 1e-13;
     const double mu = sturm_largest_wave<LDS, PRIO>(L, np, lane, lo, hi, rounds, &prio);
     prio.finish();
-    return mu;
+    return brk ? fmax(mu, (double)(dmax + 1)) : mu;
 }
 
 // ---- two eigenproblems per wave (n' <= 32 each) ----------------------------------------------------------
@@ -891,8 +943,10 @@ __device__ __forceinline__ double half_lane(double v, int src, bool upper) {   /
 
 // mu_max of both problems; `crow` = the lane's 32-bit complement row, np = max(n'_A, n'_B) <= 32, np_own = the
 // size of the lane's own problem (0: no problem in this half).  The result is valid in every lane of a half.
+// tw: the lane's problem is a quotient by twin classes (sc: 64 doubles of LDS for the column scales).
 template <class LDS, bool PRIO = false>
-__device__ __forceinline__ double mu_max_pair_wave(uint32_t crow, int np, int np_own, int lane, LDS& L, int rounds) {
+__device__ __forceinline__ double mu_max_pair_wave(uint32_t crow, int np, int np_own, int lane, LDS& L, int rounds,
+                                                   TwinInfo tw = TwinInfo(), double* sc = nullptr) {
     constexpr int NPAD = 32, KB = 2;
     const bool upper = lane >= 32;
     const int hl = lane & 31;
@@ -903,8 +957,22 @@ __device__ __forceinline__ double mu_max_pair_wave(uint32_t crow, int np, int np
     dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, 0x122, 0xF, 0xF, false));
     dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, 0x121, 0xF, 0xF, false));
     dmax = max(dmax, __builtin_amdgcn_ds_swizzle(dmax, 0x401F));
+    const bool weighted = ballot64(tw.brk != 0) != 0;           // either problem is a quotient
+    int npb = np_own, diag = cdeg;
+    double s = 1.0;
+    if (tw.brk) {
+        dmax = tw.brk >> 8;
+        npb = tw.brk & 0xFF;
+        diag = tw.meta >> 8;
+        s = sqrt((double)(tw.meta & 0xFF));
+    }
     double a[NPAD];
-    {
+    if (weighted) {
+        WSYNC();
+        sc[lane] = s;
+        WSYNC();
+        quotient_row_registers<NPAD, true>((uint64_t)crow, diag, s, sc + (lane & 32), a);
+    } else {
         const double dg = (double)cdeg;
         const int dg_hi = __double2hiint(dg), dg_lo = __double2loint(dg);
         static_for<0, NPAD>([&](auto k) {
@@ -916,7 +984,8 @@ __device__ __forceinline__ double mu_max_pair_wave(uint32_t crow, int np, int np
             a[c] = __hiloint2double(hi, lo);
         });
     }
-    double col = (hl == np - 1) ? (double)cdeg : -(double)((crow >> (np - 1)) & 1u);
+    double col = (hl == np - 1) ? (double)diag : -(double)((crow >> (np - 1)) & 1u);
+    if (weighted && hl != np - 1) col *= s * sc[(lane & 32) + np - 1];
     SolvePriority<PRIO> prio;
     prio.start(SolvePriority<PRIO>::work(np, rounds), SolvePriority<PRIO>::work(NPAD, rounds));
     for (int i = np - 1; i >= 2; --i) {
@@ -963,7 +1032,7 @@ __device__ __forceinline__ double mu_max_pair_wave(uint32_t crow, int np, int np
     // 32-way multisection per half on the Sturm sign changes (see sturm_largest_wave); the padded rows are zero
     // eigenvalues, below every x of the bracket, so "all np eigenvalues below x" is the test in both halves.
     double lo = (double)(dmax + 1) * (1.0 - 1e-13) - 1e-13;
-    double hi = (double)min(np_own, 2 * dmax) * (1.0 + 1e-13) + 1e-13;
+    double hi = (double)min(npb, 2 * dmax) * (1.0 + 1e-13) + 1e-13;
     const double2* de = L.de + (lane & 32);
     for (int r = 0; r < rounds; ++r) {
         const bool active = (hi - lo) > 1e-11 * hi;
@@ -1013,19 +1082,22 @@ __device__ __forceinline__ double mu_max_pair_wave(uint32_t crow, int np, int np
         }
     }
     prio.finish();
-    return 0.5 * (lo + hi);
+    const double mu = 0.5 * (lo + hi);
+    return tw.brk ? fmax(mu, (double)(dmax + 1)) : mu;
 }
 
 // mu_max of one eigenproblem inside a wave, by the solver the step's solve launch would use for it: problems of
 // at most 32 vertices go through the two-per-wave code (alone, the upper half idle), so that the result does not
 // depend on the schedule; larger ones through the 64-lane solver.
 template <int NPAD, class LDS, bool LANCZOS = false>
-__device__ __forceinline__ double mu_max_in_wave(uint64_t crow, int np, int lane, LDS& L, int rounds, double nfull) {
+__device__ __forceinline__ double mu_max_in_wave(uint64_t crow, int np, int lane, LDS& L, int rounds, double nfull,
+                                                 TwinInfo tw = TwinInfo(), double* sc = nullptr) {
     if (np <= 32) {
         const bool upper = lane >= 32;
-        return readlane_d(mu_max_pair_wave(upper ? 0u : (uint32_t)crow, np, upper ? 0 : np, lane, L, rounds + 2), 0);
+        if (upper) tw = TwinInfo();
+        return readlane_d(mu_max_pair_wave(upper ? 0u : (uint32_t)crow, np, upper ? 0 : np, lane, L, rounds + 2, tw, sc), 0);
     }
-    if constexpr (NPAD > 32) return mu_max_compact_wave<NPAD, LDS, false, LANCZOS>(crow, np, lane, L, rounds, nfull);
+    if constexpr (NPAD > 32) return mu_max_compact_wave<NPAD, LDS, false, LANCZOS>(crow, np, lane, L, rounds, nfull, tw, sc);
     return 0.0;
 }
 
@@ -1038,8 +1110,92 @@ __device__ __forceinline__ double mu_max_in_wave(uint64_t crow, int np, int lane
 //     the space orthogonal to the all-ones vector the spectra mirror each other.  Only
 //     the n' vertices that miss at least one neighbour carry edges of the complement;
 //     they are compacted to lanes 0..n'-1 and handed to mu_max_compact_wave.
+// Twin vertices.  Two vertices of the complement with the same neighbours (not adjacent to each other: "open" twins,
+// N(a) = N(b)) or the same neighbours and each other (adjacent, "closed" twins, N[a] = N[b]) span an eigenvector
+// e_a - e_b of its Laplacian, with the eigenvalue deg or deg + 1 -- never above dmax + 1, which the largest eigenvalue
+// of a graph with an edge reaches anyway.  Every other eigenvector is constant on a class of twins, so the rest of
+// the spectrum is that of the quotient: one vertex per class, Q_ii = the sum of the multiplicities m_j of the
+// neighbouring classes, Q_ij = -sqrt(m_i m_j) between neighbours, and
+//     mu_max(L) = max(mu_max(Q), dmax + 1).
+// The graphs of a step have many (links missing towards the same far vertex, enemies jammed by the same jammer): a
+// fifth of the tridiagonalisation's work at 50 vertices.
+//
+// What the solvers need to know about a merged problem: per lane (vertex of the quotient) `meta` = m | Q_ii << 8; per
+// problem `brk` = n' | dmax << 8 of the graph before merging, which bracket the eigenvalue (0: nothing was merged and the
+// matrix is the plain Laplacian of the bit rows).
+constexpr int TWIN_MIN_NP = 12;          // smaller problems are not searched: the search costs what a few Householder steps do
+
+// The bits of `row` at the set positions of `keep`, packed towards bit 0: one step per run of consecutive positions
+// (`keep` is wave-uniform).
+__device__ __forceinline__ uint64_t compress_bits(uint64_t row, uint64_t keep) {
+    uint64_t out = 0;
+    int k = 0;
+    while (keep) {
+        const int a = __ffsll((unsigned long long)keep) - 1;
+        const uint64_t inv = ~(keep >> a);                   // zero bits mark the end of the run
+        const int len = inv ? __ffsll((unsigned long long)inv) - 1 : 64;
+        const uint64_t ones = (len >= 64) ? ~0ull : ((1ull << len) - 1);
+        out |= ((row >> a) & ones) << k;
+        k += len;
+        keep = (a + len >= 64) ? 0ull : (keep & ~(ones << a));
+    }
+    return out;
+}
+
+// Merges the twins among the np vertices whose rows are `crow` (lane j < np: row j).  Classes are found through a
+// hash table in LDS (a slot per 9-bit hash of the row, the last writer stays): every vertex compares its row with the
+// one of its slot's owner, so a merge always rests on an exact comparison and a collision only leaves twins unmerged.
+__device__ __forceinline__ void merge_twins(uint64_t& crow, int& np, int lane, WaveLds& L, TwinInfo& tw) {
+    tw.meta = 0; tw.brk = 0;
+    if (np < TWIN_MIN_NP) return;
+    const bool valid = lane < np;
+    const uint64_t self = 1ull << lane;
+    unsigned char* table = reinterpret_cast<unsigned char*>(L.xfer);        // 512 slots
+    int* count = reinterpret_cast<int*>(L.xfer);
+    int rep = -1, add = 0;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {             // open twins, then closed ones (a vertex cannot have both kinds)
+        const uint64_t key = pass ? (crow | self) : crow;
+        const uint32_t h = ((uint32_t)key * 0x9E3779B1u + (uint32_t)(key >> 32) * 0x85EBCA77u) >> 23;
+        WSYNC();
+        if (valid) table[h] = (unsigned char)lane;
+        WSYNC();
+        const int r = valid ? (int)table[h] : lane;
+        const uint64_t key_r = ((uint64_t)(uint32_t)__shfl((int)(key >> 32), r) << 32) | (uint32_t)__shfl((int)key, r);
+        if (valid && r != lane && rep < 0 && key_r == key) { rep = r; add = pass ? 0x10001 : 1; }
+    }
+    const uint64_t merged = ballot64(rep >= 0);
+    if (merged == 0 || np - __popcll(merged) < 2) return;      // (one class of closed twins, a complete graph: left as it is)
+    WSYNC();
+    count[lane] = 0;
+    WSYNC();
+    if (rep >= 0) atomicAdd(&count[rep], add);
+    WSYNC();
+    const int c = count[lane];
+    const int mult = 1 + (c & 0xFFFF);
+    const int deg = __popcll(crow);
+    int dmax = valid ? deg : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
+    const int qii = deg - ((c >> 16) ? mult - 1 : 0);        // the members of a closed class are neighbours of each other
+    const uint64_t keep = ballot64(valid && rep < 0);
+    const int pos = __popcll(keep & (self - 1));
+    const uint64_t packed = compress_bits(crow & keep, keep);
+    WSYNC();
+    if ((keep >> lane) & 1ull) L.xfer[pos] = packed;
+    WSYNC();
+    tw.brk = np | (dmax << 8);
+    np = __popcll(keep);
+    crow = (lane < np) ? L.xfer[lane] : 0ull;
+    WSYNC();
+    if ((keep >> lane) & 1ull) count[pos] = mult | (qii << 8);
+    WSYNC();
+    tw.meta = (lane < np) ? count[lane] : 0;
+}
+
 // Everything before the eigen-solve: returns true when lambda2 is already known (in `lam`),
-// false when the complement rows `crow` of the np compacted vertices have to be solved.
+// false when the complement rows `crow` of the np compacted vertices have to be solved (merge_twins may shrink the
+// problem before that).
 __device__ __forceinline__ bool lambda2_prepare(uint64_t row, int n, int lane, WaveLds& L, double& lam, uint64_t& crow, int& np) {
     crow = 0; np = 0; lam = 0.0;
     if (n <= 1) return true;
@@ -1059,20 +1215,7 @@ __device__ __forceinline__ bool lambda2_prepare(uint64_t row, int n, int lane, W
     }
     // complement rows restricted to the touched vertices, compacted
     np = __popcll(touched);
-    const uint64_t crow_full = ~row & active & ~(1ull << lane) & touched;
-    {   // one step per run of consecutive touched vertices
-        uint64_t t = touched;
-        int k = 0;
-        while (t) {
-            const int a = __ffsll((unsigned long long)t) - 1;
-            const uint64_t inv = ~(t >> a);                      // zero bits mark the end of the run
-            const int len = inv ? __ffsll((unsigned long long)inv) - 1 : 64;
-            const uint64_t ones = (len >= 64) ? ~0ull : ((1ull << len) - 1);
-            crow |= ((crow_full >> a) & ones) << k;
-            k += len;
-            t = (a + len >= 64) ? 0ull : (t & ~(ones << a));
-        }
-    }
+    crow = compress_bits(~row & active & ~(1ull << lane) & touched, touched);
     WSYNC();
     if ((touched >> lane) & 1ull) L.xfer[__popcll(touched & ((1ull << lane) - 1))] = crow;
     WSYNC();
@@ -1085,8 +1228,10 @@ __device__ __forceinline__ double lambda2_wave(uint64_t row, int n, int lane, Wa
     double lam;
     uint64_t crow;
     int np;
+    TwinInfo tw;
     if (lambda2_prepare(row, n, lane, L, lam, crow, np)) return lam;
-    return (double)n - mu_max_in_wave<NPAD, WaveLds, LANCZOS>(crow, np, lane, L, rounds, (double)n);
+    merge_twins(crow, np, lane, L, tw);
+    return (double)n - mu_max_in_wave<NPAD, WaveLds, LANCZOS>(crow, np, lane, L, rounds, (double)n, tw, L.scale);
 }
 
 // ------------------------------------------------------------------ DBSCAN + centroids
@@ -1525,10 +1670,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 
     double lam;
     uint64_t crow;
     int np;
+    TwinInfo tw;
     bool final_lam = lambda2_prepare(adj & ~jam, n, lane, L, lam, crow, np);
     if constexpr (FUSED > 0) {
         if (!final_lam) {
-            lam = (double)n - mu_max_in_wave<FUSED>(crow, np, lane, L, P.lambda2_rounds, (double)n);
+            merge_twins(crow, np, lane, L, tw);
+            lam = (double)n - mu_max_in_wave<FUSED>(crow, np, lane, L, P.lambda2_rounds, (double)n, tw, L.scale);
             final_lam = true;
             np = 0;
         }
@@ -1546,13 +1693,20 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 
     }
     double avgp = 0.0;
     if (io.avg_power_dbm) avgp = avg_power_wave(P, n, m, lane, L, eband);
-    if (FUSED == 0 && !final_lam && lane < np) S.solve_rows[(size_t)e * WAVE + lane] = crow;
+    if (FUSED == 0 && !final_lam) {
+        // (here and not before the reward: the search for twins has the registers of the reward's inputs to itself)
+        merge_twins(crow, np, lane, L, tw);
+        if (lane < np) {
+            S.solve_rows[(size_t)e * WAVE + lane] = crow;
+            if (tw.brk) S.solve_meta[(size_t)e * WAVE + lane] = (uint16_t)tw.meta;
+        }
+    }
     if (lane == 0) {
         S.step_count[e] = step;
         S.tick[e] = tick;
         io.truncated[e] = (uint8_t)(step >= P.max_steps);
         if (io.avg_power_dbm) io.avg_power_dbm[e] = avgp;
-        if (FUSED == 0) S.solve_np[e] = np;
+        if (FUSED == 0) S.solve_np[e] = np | (tw.brk << 8);
         if (final_lam) {
             finish_env(P, S, io, e, step, rw.total, lam, lam0);
         } else {
@@ -1611,7 +1765,7 @@ __global__ __launch_bounds__(1024) void solve_order_kernel(int E, MarlEnvState S
     __syncthreads();
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < E) {
-        const int np = S.solve_np[e];
+        const int np = S.solve_np[e] & 0xFF;
         if (np > 0) {
             S.solve_perm[start[e & (SOLVE_HIST_SUBS - 1)][np] + S.solve_slot[e]] = e;
         }
@@ -1620,6 +1774,7 @@ __global__ __launch_bounds__(1024) void solve_order_kernel(int E, MarlEnvState S
 
 struct SolveLds {
     double2 de[WAVE];
+    double scale[WAVE];        // column scales of a quotient by twin classes
 };
 
 #ifdef MARL_EXP_BLOCKTIME
@@ -1652,11 +1807,15 @@ __device__ __forceinline__ void solve_item(const MarlEnvParams& P, const MarlEnv
     if (item >= nbig) {
         const int k = nbig + 2 * (item - nbig);
         const int eA = S.solve_perm[k], eB = (k + 1 < total) ? S.solve_perm[k + 1] : -1;
-        const int npA = S.solve_np[eA], npB = (eB >= 0) ? S.solve_np[eB] : 0;      // sorted: npA >= npB
+        const int wA = S.solve_np[eA], wB = (eB >= 0) ? S.solve_np[eB] : 0;        // n' | quotient bracket << 8
+        const int npA = wA & 0xFF, npB = wB & 0xFF;                                 // sorted: npA >= npB
         const bool upper = lane >= 32;
         const int e = upper ? eB : eA, np_own = upper ? npB : npA, hl = lane & 31;
         const uint32_t crow = (e >= 0 && hl < np_own) ? (uint32_t)S.solve_rows[(size_t)e * WAVE + hl] : 0u;
-        const double mu = mu_max_pair_wave<SolveLds, PRIO>(crow, npA, np_own, lane, L, P.lambda2_rounds + 2);
+        TwinInfo tw;
+        tw.brk = (upper ? wB : wA) >> 8;
+        if (tw.brk && hl < np_own) tw.meta = S.solve_meta[(size_t)e * WAVE + hl];
+        const double mu = mu_max_pair_wave<SolveLds, PRIO>(crow, npA, np_own, lane, L, P.lambda2_rounds + 2, tw, L.scale);
         if (hl == 0 && e >= 0) {
             const double lam = (double)P.N - mu;
             const double* part = S.solve_partial + (size_t)e * 4;
@@ -1672,9 +1831,12 @@ __device__ __forceinline__ void solve_item(const MarlEnvParams& P, const MarlEnv
         return;
     }
     const int e = S.solve_perm[item];
-    const int np = S.solve_np[e];
+    const int np = S.solve_np[e] & 0xFF;
     const uint64_t crow = (lane < np) ? S.solve_rows[(size_t)e * WAVE + lane] : 0ull;
-    const double lam = (double)P.N - mu_max_compact_wave<NPAD, SolveLds, PRIO, LANCZOS>(crow, np, lane, L, P.lambda2_rounds, (double)P.N);
+    TwinInfo tw;
+    tw.brk = S.solve_np[e] >> 8;
+    if (tw.brk && lane < np) tw.meta = S.solve_meta[(size_t)e * WAVE + lane];
+    const double lam = (double)P.N - mu_max_compact_wave<NPAD, SolveLds, PRIO, LANCZOS>(crow, np, lane, L, P.lambda2_rounds, (double)P.N, tw, L.scale);
     if (lane == 0) {
         const double* part = S.solve_partial + (size_t)e * 4;
         double r1;
@@ -3698,6 +3860,7 @@ size_t marl_state_bytes(const MarlEnvParams* p, int32_t E) {
     b += align256(workspace_bytes(p->N, E)); // lambda2 matrix workspace (N > 64 only)
     if (p->N <= WAVE) {                      // hand-over from the front kernel to the solve kernel
         b += align256(e * WAVE * 8);         // solve_rows
+        b += align256(e * WAVE * 2);         // solve_meta
         b += 3 * align256(e * 4);            // solve_np, solve_slot, solve_perm
         b += align256(SOLVE_HIST_WORDS * 4); // solve_hist
     }
@@ -3735,6 +3898,7 @@ int marl_state_bind(MarlEnvState* s, const MarlEnvParams* p, int32_t E, void* ba
     s->workspace = wsb ? (double*)take(wsb) : nullptr;
     const bool split = p->N <= WAVE;
     s->solve_rows = split ? (uint64_t*)take(e * WAVE * 8) : nullptr;
+    s->solve_meta = split ? (uint16_t*)take(e * WAVE * 2) : nullptr;
     s->solve_np = split ? (int32_t*)take(e * 4) : nullptr;
     s->solve_slot = split ? (int32_t*)take(e * 4) : nullptr;
     s->solve_perm = split ? (int32_t*)take(e * 4) : nullptr;
@@ -3763,7 +3927,7 @@ int marl_state_shard(const MarlEnvParams* p, const MarlEnvState* whole, int32_t 
     move(out->labels, n); move(out->cent_x, ks); move(out->cent_y, ks); move(out->cent_size, ks);
     move(out->n_clusters, 1); move(out->ncent, 1); move(out->prev_x, ks); move(out->prev_y, ks);
     move(out->prev_n_clusters, 1); move(out->prev_ncent, 1); move(out->assign, m);
-    move(out->solve_rows, WAVE); move(out->solve_np, 1); move(out->solve_slot, 1); move(out->solve_perm, 1);
+    move(out->solve_rows, WAVE); move(out->solve_meta, WAVE); move(out->solve_np, 1); move(out->solve_slot, 1); move(out->solve_perm, 1);
     move(out->solve_partial, 4); move(out->episode_return, 1);
     out->solve_hist = (int32_t*)scratch;
     return MARL_OK;
@@ -3799,7 +3963,7 @@ static int step_launches(const MarlEnvParams* p, const MarlEnvState* s, const Ma
         if (after != nullptr && (rc = hip_check(hipEventRecord(after, (hipStream_t)stream))) != MARL_OK) return rc;
         return hip_check(hipGetLastError());
     }
-    if (s->solve_rows == nullptr || s->solve_np == nullptr || s->solve_slot == nullptr || s->solve_perm == nullptr ||
+    if (s->solve_rows == nullptr || s->solve_meta == nullptr || s->solve_np == nullptr || s->solve_slot == nullptr || s->solve_perm == nullptr ||
         s->solve_hist == nullptr || s->solve_partial == nullptr)
         return MARL_EINVAL;
     const bool fused = p->step_schedule == MARL_SCHEDULE_FUSED ||

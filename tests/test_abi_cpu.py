@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header_layout():
     # 10 int32 + 20 double + 12 double + 4 float
     assert C.sizeof(_lib.MarlEnvParams) == 10 * 4 + 32 * 8 + 12 * 4
-    assert C.sizeof(_lib.MarlEnvState) == 8 + 33 * 8
+    assert C.sizeof(_lib.MarlEnvState) == 8 + 34 * 8
     assert C.sizeof(_lib.MarlStepIO) == 13 * 8
     assert C.sizeof(_lib.MarlPolicyIO) == 9 * 8
     assert C.sizeof(_lib.MarlResetIO) == 11 * 8
@@ -80,7 +80,7 @@ def test_state_carving_is_disjoint_and_aligned():
     base = 0x10000000
     _lib.check(lib.marl_state_bind(C.byref(st), C.byref(p), E, C.c_void_p(base)))
     assert st.workspace is None                       # N <= 64 needs no lambda2 scratch
-    assert st.solve_rows is not None and st.solve_partial is not None
+    assert st.solve_rows is not None and st.solve_meta is not None and st.solve_partial is not None
     ptrs = sorted(getattr(st, n) for n in _lib._STATE_ARRAYS if n != "workspace")
     assert ptrs[0] == base and all(q % 256 == 0 for q in ptrs)
     assert len(set(ptrs)) == len(ptrs) and ptrs[-1] < base + nbytes
