@@ -738,9 +738,9 @@ __device__ __forceinline__ double sturm_largest_wave(const LDS& L, int np, int l
 #else
 #define TSTAMP(k, pin)
 #endif
-// An eigenproblem whose twin vertices have been merged (merge_twins): per lane (vertex of the quotient) `meta` =
-// multiplicity | diagonal entry << 8; per problem `brk` = n' | dmax << 8 of the graph before merging, which bracket the
-// eigenvalue (0: nothing was merged, the matrix is the plain Laplacian of the bit rows).
+// An eigenproblem that reduce_problem has worked on: per lane (vertex of the quotient by twin classes) `meta` =
+// multiplicity | diagonal entry << 8; per problem `brk` = n' | dmax << 8 of the graph before the reduction, which bracket
+// the eigenvalue (0: nothing was done, the matrix is the plain Laplacian of the bit rows).
 struct TwinInfo {
     int meta = 0, brk = 0;
 };
@@ -816,11 +816,14 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
     constexpr int KB = (NPAD + 15) / 16;
     // a quotient: the bracket is the one of the graph before merging, the matrix has weights
     const int brk = __builtin_amdgcn_readfirstlane(tw.brk);
+    const bool weighted = brk && ballot64((tw.meta & 0xFF) > 1) != 0;       // (components dropped, no twins: plain rows)
     int npb = np, diag = cdeg;
     double s = 1.0;
     if (brk) {
         dmax = brk >> 8;
         npb = brk & 0xFF;
+    }
+    if (weighted) {
         diag = tw.meta >> 8;
         s = sqrt((double)(tw.meta & 0xFF));
         WSYNC();
@@ -834,7 +837,7 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
             double mu;
             // (the iteration works on a register matrix of its own, built a second time below if the direct solver has to
             // take over, which is rare: one set of registers live through both solvers costs the kernel a wave per SIMD)
-            if (mu_max_lanczos_wave<NPAD, LDS, PRIO>(crow, diag, np, lane, dmax, npb, brk ? sc : nullptr, s, nfull, L, rounds, prio, mu)) {
+            if (mu_max_lanczos_wave<NPAD, LDS, PRIO>(crow, diag, np, lane, dmax, npb, weighted ? sc : nullptr, s, nfull, L, rounds, prio, mu)) {
                 prio.finish();
                 return brk ? fmax(mu, (double)(dmax + 1)) : mu;
             }
@@ -848,7 +851,7 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
     }
     double a[NPAD];                                   // row `lane` of the matrix
     // (pinned: statements that may be hoisted out of the branch would keep both builds in registers at once)
-    if (brk) quotient_row_registers<NPAD>(crow, diag, s, sc, a);
+    if (weighted) quotient_row_registers<NPAD>(crow, diag, s, sc, a);
     else laplacian_row_registers<NPAD, true>(crow, cdeg, a);
 
 #ifdef MARL_EXP_TIMING
@@ -858,7 +861,7 @@ __device__ __forceinline__ double mu_max_compact_wave(uint64_t crow, int np, int
 #endif
     // pivot column A[lane][i]: the first one from the bits, the later ones handed back by the update
     double col = (lane == np - 1) ? (double)diag : -(double)((crow >> (np - 1)) & 1ull);
-    if (brk && lane != np - 1) col *= s * sc[np - 1];
+    if (weighted && lane != np - 1) col *= s * sc[np - 1];
     for (int i = np - 1; i >= 2; --i) {
         const int l = i - 1;
         prio.spend(85 + 3 * i);
@@ -957,12 +960,14 @@ __device__ __forceinline__ double mu_max_pair_wave(uint32_t crow, int np, int np
     dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, 0x122, 0xF, 0xF, false));
     dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, 0x121, 0xF, 0xF, false));
     dmax = max(dmax, __builtin_amdgcn_ds_swizzle(dmax, 0x401F));
-    const bool weighted = ballot64(tw.brk != 0) != 0;           // either problem is a quotient
+    const bool weighted = ballot64((tw.meta & 0xFF) > 1) != 0;           // either problem has merged twins
     int npb = np_own, diag = cdeg;
     double s = 1.0;
     if (tw.brk) {
         dmax = tw.brk >> 8;
         npb = tw.brk & 0xFF;
+    }
+    if (weighted && tw.brk) {
         diag = tw.meta >> 8;
         s = sqrt((double)(tw.meta & 0xFF));
     }
@@ -1109,21 +1114,29 @@ __device__ __forceinline__ double mu_max_in_wave(uint64_t crow, int np, int lane
 //   * otherwise lambda2(G) = n - mu_max(complement of G): L(G) + L(G') = n I - J, so on
 //     the space orthogonal to the all-ones vector the spectra mirror each other.  Only
 //     the n' vertices that miss at least one neighbour carry edges of the complement;
-//     they are compacted to lanes 0..n'-1 and handed to mu_max_compact_wave.
-// Twin vertices.  Two vertices of the complement with the same neighbours (not adjacent to each other: "open" twins,
-// N(a) = N(b)) or the same neighbours and each other (adjacent, "closed" twins, N[a] = N[b]) span an eigenvector
-// e_a - e_b of its Laplacian, with the eigenvalue deg or deg + 1 -- never above dmax + 1, which the largest eigenvalue
-// of a graph with an edge reaches anyway.  Every other eigenvector is constant on a class of twins, so the rest of
-// the spectrum is that of the quotient: one vertex per class, Q_ii = the sum of the multiplicities m_j of the
-// neighbouring classes, Q_ij = -sqrt(m_i m_j) between neighbours, and
-//     mu_max(L) = max(mu_max(Q), dmax + 1).
-// The graphs of a step have many (links missing towards the same far vertex, enemies jammed by the same jammer): a
-// fifth of the tridiagonalisation's work at 50 vertices.
+//     they are compacted to lanes 0..n'-1 (lambda2_prepare), the problem is reduced where its
+//     structure allows (reduce_problem) and handed to mu_max_compact_wave / mu_max_pair_wave.
 //
-// What the solvers need to know about a merged problem: per lane (vertex of the quotient) `meta` = m | Q_ii << 8; per
-// problem `brk` = n' | dmax << 8 of the graph before merging, which bracket the eigenvalue (0: nothing was merged and the
-// matrix is the plain Laplacian of the bit rows).
-constexpr int TWIN_MIN_NP = 12;          // smaller problems are not searched: the search costs what a few Householder steps do
+// Reductions that keep mu_max.  The largest Laplacian eigenvalue of a graph with an edge is at least dmax + 1 (dmax its
+// largest degree), so whatever cannot exceed that need not be solved:
+//   * Components.  mu_max is the largest over the components, and a component of c vertices stays at or below c:
+//     those of at most dmax + 1 vertices are dropped.  If none is left, mu_max = dmax + 1 (the component of the vertex of
+//     largest degree has exactly that many vertices, all of them its neighbours) and there is no eigenproblem at all.
+//   * Twins.  Two vertices with the same neighbours (not adjacent to each other: "open" twins, N(a) = N(b)) or the
+//     same neighbours and each other ("closed" twins, N[a] = N[b]) span an eigenvector e_a - e_b with the eigenvalue deg
+//     or deg + 1.  Every other eigenvector is constant on a class of twins, so the rest of the spectrum is that of the
+//     quotient: one vertex per class, Q_ii = the sum of the multiplicities m_j of the neighbouring classes,
+//     Q_ij = -sqrt(m_i m_j) between neighbours.
+// Together: mu_max(L) = max(mu_max(Q restricted to the large components), dmax + 1).  The graphs of a step have plenty
+// of both (links missing towards the same far vertex, enemies jammed by the same jammer, small groups cut off
+// together): 30 % of the tridiagonalisation's work, and a quarter of the eigenproblems vanish.
+//
+// What the solvers need to know about a reduced problem: per lane (vertex of the quotient) `meta` = m | Q_ii << 8; per
+// problem `brk` = n' | dmax << 8 of the graph before the reduction, which bracket the eigenvalue (0: nothing was done and
+// the matrix is the plain Laplacian of the bit rows).
+#ifndef REDUCE_MIN_NP
+#define REDUCE_MIN_NP 6                  /* smaller problems are left alone: the search costs what a few Householder steps do */
+#endif
 
 // The bits of `row` at the set positions of `keep`, packed towards bit 0: one step per run of consecutive positions
 // (`keep` is wave-uniform).
@@ -1142,14 +1155,49 @@ __device__ __forceinline__ uint64_t compress_bits(uint64_t row, uint64_t keep) {
     return out;
 }
 
-// Merges the twins among the np vertices whose rows are `crow` (lane j < np: row j).  Classes are found through a
-// hash table in LDS (a slot per 9-bit hash of the row, the last writer stays): every vertex compares its row with the
-// one of its slot's owner, so a merge always rests on an exact comparison and a collision only leaves twins unmerged.
-__device__ __forceinline__ void merge_twins(uint64_t& crow, int& np, int lane, WaveLds& L, TwinInfo& tw) {
+// Reduces the problem on the np vertices whose rows are `crow` (lane j < np: row j) as described above; np = 0 on
+// return: no eigenproblem is left, mu_max = dmax + 1 with dmax = tw.brk >> 8.  Twin classes are found through a hash
+// table in LDS (a slot per 9-bit hash of the row, the last writer stays): every vertex compares its row with the one of
+// its slot's owner, so a merge always rests on an exact comparison and a collision only leaves twins unmerged.
+__device__ __forceinline__ void reduce_problem(uint64_t& crow, int& np, int lane, WaveLds& L, TwinInfo& tw) {
     tw.meta = 0; tw.brk = 0;
-    if (np < TWIN_MIN_NP) return;
-    const bool valid = lane < np;
+    if (np < REDUCE_MIN_NP) return;
     const uint64_t self = 1ull << lane;
+    const uint64_t all = (np >= 64) ? ~0ull : ((1ull << np) - 1);
+    const int deg = __popcll(crow);
+    int dmax = deg;                                        // (rows beyond np are zero)
+    dmax = max(dmax, dpp_mov32<0x128>(dmax));              // row_ror:8, 4, 2, 1: the largest of every row of 16 lanes
+    dmax = max(dmax, dpp_mov32<0x124>(dmax));
+    dmax = max(dmax, dpp_mov32<0x122>(dmax));
+    dmax = max(dmax, dpp_mov32<0x121>(dmax));
+    dmax = max(max(__builtin_amdgcn_readlane(dmax, 0), __builtin_amdgcn_readlane(dmax, 16)),
+               max(__builtin_amdgcn_readlane(dmax, 32), __builtin_amdgcn_readlane(dmax, 48)));
+    // Components of more than dmax + 1 vertices.  The search starts at a vertex of the largest degree, whose component is
+    // usually the only large one: once no more than dmax + 1 vertices are left unvisited, whatever components they form
+    // are small and need not be told apart.
+    uint64_t large = 0, unvisited = all;
+    uint64_t comp = ballot64(deg == dmax);
+    comp &= 0ull - comp;
+    while (true) {
+        uint64_t frontier = comp;
+        while (frontier) {
+            const uint64_t hit = ballot64((crow & frontier) != 0);
+            const uint64_t nw = hit & ~comp;
+            comp |= nw;
+            frontier = nw;
+        }
+        if (__popcll(comp) > dmax + 1) large |= comp;
+        unvisited &= ~comp;
+        if (__popcll(unvisited) <= dmax + 1) break;
+        comp = unvisited & (0ull - unvisited);
+    }
+    if (large == 0) {
+        tw.brk = np | (dmax << 8);
+        np = 0;
+        crow = 0;
+        return;
+    }
+    const bool valid = (large >> lane) & 1ull;
     unsigned char* table = reinterpret_cast<unsigned char*>(L.xfer);        // 512 slots
     int* count = reinterpret_cast<int*>(L.xfer);
     int rep = -1, add = 0;
@@ -1165,20 +1213,19 @@ __device__ __forceinline__ void merge_twins(uint64_t& crow, int& np, int lane, W
         if (valid && r != lane && rep < 0 && key_r == key) { rep = r; add = pass ? 0x10001 : 1; }
     }
     const uint64_t merged = ballot64(rep >= 0);
-    if (merged == 0 || np - __popcll(merged) < 2) return;      // (one class of closed twins, a complete graph: left as it is)
-    WSYNC();
-    count[lane] = 0;
-    WSYNC();
-    if (rep >= 0) atomicAdd(&count[rep], add);
-    WSYNC();
-    const int c = count[lane];
-    const int mult = 1 + (c & 0xFFFF);
-    const int deg = __popcll(crow);
-    int dmax = valid ? deg : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
-    const int qii = deg - ((c >> 16) ? mult - 1 : 0);        // the members of a closed class are neighbours of each other
-    const uint64_t keep = ballot64(valid && rep < 0);
+    if (merged == 0 && large == all) return;               // nothing to drop, nothing to merge
+    int mult = 1, qii = deg;
+    if (merged) {
+        WSYNC();
+        count[lane] = 0;
+        WSYNC();
+        if (rep >= 0) atomicAdd(&count[rep], add);
+        WSYNC();
+        const int c = count[lane];
+        mult = 1 + (c & 0xFFFF);
+        qii = deg - ((c >> 16) ? mult - 1 : 0);            // the members of a closed class are neighbours of each other
+    }
+    const uint64_t keep = large & ~merged;
     const int pos = __popcll(keep & (self - 1));
     const uint64_t packed = compress_bits(crow & keep, keep);
     WSYNC();
@@ -1194,7 +1241,7 @@ __device__ __forceinline__ void merge_twins(uint64_t& crow, int& np, int lane, W
 }
 
 // Everything before the eigen-solve: returns true when lambda2 is already known (in `lam`),
-// false when the complement rows `crow` of the np compacted vertices have to be solved (merge_twins may shrink the
+// false when the complement rows `crow` of the np compacted vertices have to be solved (reduce_problem may shrink the
 // problem before that).
 __device__ __forceinline__ bool lambda2_prepare(uint64_t row, int n, int lane, WaveLds& L, double& lam, uint64_t& crow, int& np) {
     crow = 0; np = 0; lam = 0.0;
@@ -1230,7 +1277,8 @@ __device__ __forceinline__ double lambda2_wave(uint64_t row, int n, int lane, Wa
     int np;
     TwinInfo tw;
     if (lambda2_prepare(row, n, lane, L, lam, crow, np)) return lam;
-    merge_twins(crow, np, lane, L, tw);
+    reduce_problem(crow, np, lane, L, tw);
+    if (np == 0) return (double)n - (double)((tw.brk >> 8) + 1);
     return (double)n - mu_max_in_wave<NPAD, WaveLds, LANCZOS>(crow, np, lane, L, rounds, (double)n, tw, L.scale);
 }
 
@@ -1674,8 +1722,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 
     bool final_lam = lambda2_prepare(adj & ~jam, n, lane, L, lam, crow, np);
     if constexpr (FUSED > 0) {
         if (!final_lam) {
-            merge_twins(crow, np, lane, L, tw);
-            lam = (double)n - mu_max_in_wave<FUSED>(crow, np, lane, L, P.lambda2_rounds, (double)n, tw, L.scale);
+            reduce_problem(crow, np, lane, L, tw);
+            lam = np == 0 ? (double)n - (double)((tw.brk >> 8) + 1)
+                          : (double)n - mu_max_in_wave<FUSED>(crow, np, lane, L, P.lambda2_rounds, (double)n, tw, L.scale);
             final_lam = true;
             np = 0;
         }
@@ -1693,9 +1742,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 
     }
     double avgp = 0.0;
     if (io.avg_power_dbm) avgp = avg_power_wave(P, n, m, lane, L, eband);
+    bool solved_late = false;
     if (FUSED == 0 && !final_lam) {
-        // (here and not before the reward: the search for twins has the registers of the reward's inputs to itself)
-        merge_twins(crow, np, lane, L, tw);
+        // (here and not before the reward: the reduction has the registers of the reward's inputs to itself)
+        reduce_problem(crow, np, lane, L, tw);
+        if (np == 0) {                      // nothing left to solve: the reward is finished below, as the solve kernel would
+            lam = (double)n - (double)((tw.brk >> 8) + 1);
+            solved_late = true;
+        }
         if (lane < np) {
             S.solve_rows[(size_t)e * WAVE + lane] = crow;
             if (tw.brk) S.solve_meta[(size_t)e * WAVE + lane] = (uint16_t)tw.meta;
@@ -1706,9 +1760,16 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 
         S.tick[e] = tick;
         io.truncated[e] = (uint8_t)(step >= P.max_steps);
         if (io.avg_power_dbm) io.avg_power_dbm[e] = avgp;
-        if (FUSED == 0) S.solve_np[e] = np | (tw.brk << 8);
+        if (FUSED == 0) S.solve_np[e] = np ? np | (tw.brk << 8) : 0;
         if (final_lam) {
             finish_env(P, S, io, e, step, rw.total, lam, lam0);
+        } else if (solved_late) {
+            double r1;
+            const double total_r = reward_total(P, lam, lam0, rw.d2, rw.d3, rw.r3, rw.d5, r1);
+            finish_env(P, S, io, e, step, total_r, lam, lam0);
+#if !defined(MARL_EXP_TIMING) && !defined(MARL_EXP_BLOCKTIME)
+            if (io.reward_terms) io.reward_terms[(size_t)e * 5] = (float)r1;
+#endif
         } else {
             S.solve_slot[e] = atomicAdd(&S.solve_hist[(e & (SOLVE_HIST_SUBS - 1)) * SOLVE_HIST_STRIDE + np], 1);
             double* part = S.solve_partial + (size_t)e * 4;

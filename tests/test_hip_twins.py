@@ -1,7 +1,8 @@
-"""Twin vertices of the complement graph are merged before the eigen-solve (same neighbours, adjacent to each other or
-not: they only contribute eigenvalues that cannot exceed the largest one).  The quantity is compute_lambda2's
+"""The eigenproblem is reduced before it is solved: twin vertices of the complement graph are merged (same neighbours,
+adjacent to each other or not: they only contribute eigenvalues that cannot exceed the largest one) and components of
+at most dmax + 1 vertices are dropped (their eigenvalues cannot either).  The quantity is compute_lambda2's
 (physics/communication_graph.py:219-286), the bar LAPACK's dsyevr as for every other solver path; the graphs here are
-built so that the merge has work to do, up to the cases where it leaves a single class or decides the eigenvalue."""
+built so that the reduction has work to do, up to the cases where nothing is left of the problem."""
 import numpy as np
 import pytest
 
@@ -34,6 +35,11 @@ def _with_twins(rng, n, count):
         if k % 3 == 2:                                             # a few edges that break some of the classes again
             extra = np.triu(rng.rand(n, n) < 0.02, 1)
             comp |= extra | extra.T
+        if k % 4 == 1 and m >= 12:                                 # small components beside the rest: a few pairs and a triangle
+            t = m - 7
+            comp[t:m, :] = comp[:, t:m] = False
+            comp[t, t + 1] = comp[t + 2, t + 3] = comp[t + 4, t + 5] = comp[t + 5, t + 6] = comp[t + 4, t + 6] = True
+            comp |= comp.T
         perm = rng.permutation(n)
         comp = comp[perm][:, perm]
         np.fill_diagonal(comp, False)
@@ -62,15 +68,21 @@ def test_graphs_with_twin_classes_against_lapack(n, solver):
 @pytest.mark.parametrize("n", [14, 32, 33, 50, 64])
 def test_closed_forms_made_of_twins(n):
     """Complements that are nothing but twins: a complete graph on k vertices (one closed class: mu_max = k), a star
-    (its leaves one open class: mu_max = k), complete bipartite and complete multipartite graphs (mu_max = k)."""
+    (its leaves one open class: mu_max = k), complete bipartite and complete multipartite graphs (mu_max = k); and
+    complements that are nothing but small components (disjoint edges, disjoint triangles)."""
     graphs, want = [], []
     for k in (n, n - 1, n - 5, 12):
-        for kind in ("clique", "star", "bipartite", "tripartite"):
+        for kind in ("clique", "star", "bipartite", "tripartite", "matching", "triangles"):
             comp = np.zeros((n, n), dtype=bool)
             if kind == "clique":
                 comp[:k, :k] = True
             elif kind == "star":
                 comp[0, 1:k] = comp[1:k, 0] = True
+            elif kind in ("matching", "triangles"):                # components of dmax + 1 vertices only: nothing to solve
+                c = 2 if kind == "matching" else 3
+                kk = k // c * c
+                i = np.arange(kk)
+                comp[:kk, :kk] = (i[:, None] // c) == (i[None, :] // c)
             else:
                 parts = 2 if kind == "bipartite" else 3
                 side = np.arange(k) % parts if kind == "tripartite" else (np.arange(k) < k // 3).astype(int)
@@ -79,7 +91,8 @@ def test_closed_forms_made_of_twins(n):
             adj = ~comp
             np.fill_diagonal(adj, False)
             graphs.append(adj)
-            want.append(float(n - k))              # mu_max = k in all four, lambda2 = n - k
+            # mu_max = k in the first four; disjoint edges: 2, disjoint triangles: 3
+            want.append(float(n - {"matching": 2, "triangles": 3}.get(kind, k)))
     graphs = np.stack(graphs)
     for sel in (_lib.LAMBDA2_DIRECT, _lib.LAMBDA2_LANCZOS):
         got = _lambda2(graphs, sel)
@@ -89,9 +102,9 @@ def test_closed_forms_made_of_twins(n):
 
 
 def test_step_graphs_are_merged_and_keep_their_lambda2():
-    """On the graphs of a step (N = 50, M = 8, random actions) the front launch hands quotients over (solve_np carries
-    the bracket of the graph before merging above bit 7) with fewer vertices than the complement had, and lambda2 of
-    those envs is LAPACK's on the adjacency bits of the same step."""
+    """On the graphs of a step (N = 50, M = 8, random actions) the front launch hands reduced problems over (solve_np
+    carries the bracket of the graph before the reduction above bit 7) with fewer vertices than the complement had, and
+    finishes others itself; lambda2 is LAPACK's on the adjacency bits of the same step."""
     import torch
     from marl_amd import BatchedJammerEnv, EnvConfig
     from oracle import jammer_oracle as orc
@@ -116,3 +129,11 @@ def test_step_graphs_are_merged_and_keep_their_lambda2():
         assert np_before[e] == int((a.sum(1) < N - 1).sum())
         want = _lapack(a)
         assert abs(lam[e] - want) <= 2e-9 * max(1.0, abs(want)), (e, lam[e], want)
+    # every env of a slice, whatever became of its problem (left alone, reduced, or gone: solve_np = 0 with a complement)
+    gone = 0
+    for e in range(300):
+        a = orc.unpack_rows(eff[e].view(np.uint32), N)
+        want = _lapack(a)
+        assert abs(lam[e] - want) <= 2e-9 * max(1.0, abs(want)), (e, lam[e], want)
+        gone += int(word[e] == 0 and want > 1e-9 and (a.sum(1) < N - 1).any())
+    assert gone > 10
