@@ -209,7 +209,7 @@ def main():
     ap.add_argument("--no-solve-priority", action="store_true",
                     help="testing: EnvConfig.solve_priority=False (the solve launch leaves the wave priority alone)")
     ap.add_argument("--solver", default="auto", choices=["auto", "direct", "lanczos"],
-                    help="testing: EnvConfig.lambda2_solver (auto: Lanczos iteration from 48 envs per CU on, else the direct solver)")
+                    help="testing: EnvConfig.lambda2_solver (auto: the direct solver up to 64 enemies, the Lanczos iteration on bit rows beyond)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")

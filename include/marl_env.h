@@ -56,9 +56,10 @@ extern "C" {
  * complement graph's Laplacian; mu_max comes from a direct solver (Householder tridiagonalisation + Sturm
  * multisection) or, for eigenproblems of 33 to 64 vertices, from a Lanczos iteration that ends when the residual
  * bound on its largest Ritz value is below 1e-6 max(1, lambda2) (the direct solver takes over if it does not get
- * there in 64 steps).  With neither selector marl_env_step chooses by the batch: the iteration from 48 envs per
- * compute unit on, where the launch is bound by the sum of its solves and not by its longest one;
- * marl_lambda2_from_bits, the reset and the one-launch (fused) step take the direct solver. */
+ * there in 64 steps).  With neither selector every entry point takes the direct solver up to 64 vertices (after the
+ * reduction of the problems -- twin vertices merged, small components dropped -- it is the faster one at every batch
+ * size measured); beyond, marl_env_step takes the iteration on the bit rows and marl_lambda2_from_bits the direct
+ * (team) solver. */
 #define MARL_LAMBDA2_DIRECT 0x100
 #define MARL_LAMBDA2_LANCZOS 0x200
 #define MARL_LAMBDA2_TEST_FEW_STEPS 0x400 /* testing, marl_lambda2_from_bits with MARL_LAMBDA2_LANCZOS at N > 64: the iteration

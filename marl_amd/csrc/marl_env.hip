@@ -1134,9 +1134,12 @@ __device__ __forceinline__ double mu_max_in_wave(uint64_t crow, int np, int lane
 // What the solvers need to know about a reduced problem: per lane (vertex of the quotient) `meta` = m | Q_ii << 8; per
 // problem `brk` = n' | dmax << 8 of the graph before the reduction, which bracket the eigenvalue (0: nothing was done and
 // the matrix is the plain Laplacian of the bit rows).
-#ifndef REDUCE_MIN_NP
-#define REDUCE_MIN_NP 6                  /* smaller problems are left alone: the search costs what a few Householder steps do */
-#endif
+// Smaller problems are left alone: the reduction costs what a few Householder steps do.  It pays from 6 vertices on
+// where the problems of a launch are sorted and paired afterwards (the three-launch step), from 12 where the wave solves
+// its own problem right away (4 096 envs x (10, 4) in one launch: 2.27 against 2.18 x 10^8 env-steps/s with 12 against
+// 6).  The limit goes by the size of the swarm (up to 16 enemies a step is one launch whatever the batch), not by the
+// schedule, so that an env's lambda2 is the same bits whichever schedule steps it.
+__device__ __forceinline__ int reduce_min_np(int n) { return n <= 16 ? 12 : 6; }
 
 // The bits of `row` at the set positions of `keep`, packed towards bit 0: one step per run of consecutive positions
 // (`keep` is wave-uniform).
@@ -1155,13 +1158,13 @@ __device__ __forceinline__ uint64_t compress_bits(uint64_t row, uint64_t keep) {
     return out;
 }
 
-// Reduces the problem on the np vertices whose rows are `crow` (lane j < np: row j) as described above; np = 0 on
+// Reduces the problem on the np vertices whose rows are `crow` (lane j < np: row j; n: the whole graph's vertices) as described above; np = 0 on
 // return: no eigenproblem is left, mu_max = dmax + 1 with dmax = tw.brk >> 8.  Twin classes are found through a hash
 // table in LDS (a slot per 9-bit hash of the row, the last writer stays): every vertex compares its row with the one of
 // its slot's owner, so a merge always rests on an exact comparison and a collision only leaves twins unmerged.
-__device__ __forceinline__ void reduce_problem(uint64_t& crow, int& np, int lane, WaveLds& L, TwinInfo& tw) {
+__device__ __forceinline__ void reduce_problem(uint64_t& crow, int& np, int n, int lane, WaveLds& L, TwinInfo& tw) {
     tw.meta = 0; tw.brk = 0;
-    if (np < REDUCE_MIN_NP) return;
+    if (np < reduce_min_np(n)) return;
     const uint64_t self = 1ull << lane;
     const uint64_t all = (np >= 64) ? ~0ull : ((1ull << np) - 1);
     const int deg = __popcll(crow);
@@ -1277,7 +1280,7 @@ __device__ __forceinline__ double lambda2_wave(uint64_t row, int n, int lane, Wa
     int np;
     TwinInfo tw;
     if (lambda2_prepare(row, n, lane, L, lam, crow, np)) return lam;
-    reduce_problem(crow, np, lane, L, tw);
+    reduce_problem(crow, np, n, lane, L, tw);
     if (np == 0) return (double)n - (double)((tw.brk >> 8) + 1);
     return (double)n - mu_max_in_wave<NPAD, WaveLds, LANCZOS>(crow, np, lane, L, rounds, (double)n, tw, L.scale);
 }
@@ -1722,7 +1725,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 
     bool final_lam = lambda2_prepare(adj & ~jam, n, lane, L, lam, crow, np);
     if constexpr (FUSED > 0) {
         if (!final_lam) {
-            reduce_problem(crow, np, lane, L, tw);
+            reduce_problem(crow, np, n, lane, L, tw);
             lam = np == 0 ? (double)n - (double)((tw.brk >> 8) + 1)
                           : (double)n - mu_max_in_wave<FUSED>(crow, np, lane, L, P.lambda2_rounds, (double)n, tw, L.scale);
             final_lam = true;
@@ -1745,7 +1748,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 
     bool solved_late = false;
     if (FUSED == 0 && !final_lam) {
         // (here and not before the reward: the reduction has the registers of the reward's inputs to itself)
-        reduce_problem(crow, np, lane, L, tw);
+        reduce_problem(crow, np, n, lane, L, tw);
         if (np == 0) {                      // nothing left to solve: the reward is finished below, as the solve kernel would
             lam = (double)n - (double)((tw.brk >> 8) + 1);
             solved_late = true;
@@ -3812,9 +3815,10 @@ size_t workspace_bytes(int N, int E) {
 // and with a spread of 1 : 2 between the fastest and the slowest solve of one size that the launch order cannot foresee.
 // A launch that the chip holds in about one round of waves is as long as its slowest solve, and the direct solver's are all
 // alike: 8 192 envs x (50, 8) on 256 CUs take 0.110 ms per step with it and 0.118 ms with the iteration (4 096 envs: 0.077
-// against 0.090).  Batches of several rounds are bound by the sum instead: 16 384 envs 0.191 against 0.167 ms.  AUTO
-// therefore takes the iteration from 48 envs per CU on.
-enum { LANCZOS_AUTO_ENVS_PER_CU = 48 };
+// against 0.090).  Batches of several rounds are bound by the sum instead, and there the iteration was ahead (16 384 envs
+// 0.191 against 0.167 ms) until the problems were reduced before the solve (reduce_problem): what is left of them suits
+// the direct solver better at every batch size measured (12 288 envs 9.7 against 8.7 x 10^7 env-steps/s, 16 384: 10.8
+// against 9.7, 65 536: 13.1 against 12.9).  AUTO therefore takes the direct solver; the iteration stays selectable.
 
 // Priorities in the solve launch pay when the launch is about one round of the chip's wave slots (16 per CU; about 0.6
 // solve blocks per env): every slot then starts a solve at once and nothing follows, so what counts is that the four
@@ -4037,8 +4041,7 @@ static int step_launches(const MarlEnvParams* p, const MarlEnvState* s, const Ma
     }
     hipLaunchKernelGGL(env_step_front_kernel<0>, dim3(s->E), dim3(WAVE), front_lds_bytes(), (hipStream_t)stream, *p, *s, *io);
     const int all_cus = cu_count();
-    const bool lanczos = p->N > 32 && (solver == MARL_LAMBDA2_LANCZOS ||
-                                       (solver == 0 && all_cus > 0 && s->E >= LANCZOS_AUTO_ENVS_PER_CU * all_cus));
+    const bool lanczos = p->N > 32 && solver == MARL_LAMBDA2_LANCZOS;
     const bool prio = !lanczos && all_cus > 0 && !(p->stage_flags & MARL_STAGE_NO_SOLVE_PRIORITY);
     hipLaunchKernelGGL(solve_order_kernel, dim3((s->E + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, (int)s->E, *s,
                        prio ? all_cus * SOLVE_WAVES_PER_CU : 0);

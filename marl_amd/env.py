@@ -63,7 +63,7 @@ class EnvConfig:
     recluster: bool = True          # False: step() never re-clusters (the table of the last reset stays): "step + reward only"
     solve_priority: bool = True     # split schedule: the issue priority of an eigen-solve follows the work it has left
     reset_shortcut: bool = True     # False (testing): the general reset kernel even where the un-jammed graph is known to be complete
-    lambda2_solver: str = "auto"    # split schedule, N > 32: "direct" (Householder), "lanczos" (iteration first), or by the batch size
+    lambda2_solver: str = "auto"    # split schedule, N > 32: "direct" (Householder), "lanczos" (iteration first); "auto": direct up to N = 64
 
     @staticmethod
     def fast_preset(N: int = 10, M: int = 4, **kw) -> "EnvConfig":
