@@ -1794,7 +1794,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(FUSED > 0 
 // between SOLVE_PRIO_ITEMS_MIN and SOLVE_PRIO_ITEMS_MAX percent of them -- about one round of waves -- runs with every
 // solve's issue priority following the work it has left (SolvePriority); the verdict goes to the solve blocks through
 // solve_hist[SOLVE_HIST_TOTAL + 2] (1 or 0).
-enum { SOLVE_PRIO_ITEMS_MIN = 99, SOLVE_PRIO_ITEMS_MAX = 130 };
+#ifndef SOLVE_PRIO_ITEMS_MIN
+#define SOLVE_PRIO_ITEMS_MIN 99
+#define SOLVE_PRIO_ITEMS_MAX 130
+#endif
 __global__ __launch_bounds__(1024) void solve_order_kernel(int E, MarlEnvState S, int prio_slots) {
     __shared__ int start[SOLVE_HIST_SUBS][WAVE + 1];
     if (threadIdx.x < WAVE) {                        // lane i stands for bin 64 - i: largest matrices first
