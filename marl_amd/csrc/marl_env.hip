@@ -650,15 +650,17 @@ struct SolvePriority {
 // k - 1 and k): the sign changes of the Sturm sequence p_0 = 1, p_k = (d_k - x) p_{k-1} - e_k^2 p_{k-2}.
 // AHEAD: 16-byte LDS reads in flight, 8 or 4 (4 registers each; the Lanczos solver's checks run beside more live state
 // than the direct solver's search and take 4).
+// last / last_exp (optional): the last term p_np of the sequence, i.e. the characteristic polynomial at x, as
+// last x 2^last_exp.
 template <int AHEAD = 8>
-__device__ __forceinline__ int sturm_count_below(const double2* de, int np, double x) {
+__device__ __forceinline__ int sturm_count_below(const double2* de, int np, double x, double* last = nullptr, int* last_exp = nullptr) {
     // The signs of p_1, p_2, ... are shifted into a 32-bit register (one v_alignbit_b32 per term);
     // with `fresh` new bits at the bottom, the sign changes they add are the set bits
     // 0..fresh-1 of B ^ (B >> 1) (bit `fresh` is the sign before them; p_0 = 1 is a zero bit).
     // Flushed before more than 31 are fresh.
     double pm = 1.0, pc = de[0].x - x;
     uint32_t bits = (uint32_t)__double2hiint(pc) >> 31;
-    int cnt = 0, fresh = 1;
+    int cnt = 0, fresh = 1, esum = 0;
     auto term = [&](int i) {
         const double2 t = de[i];
         const double pn = fma(t.x - x, pc, -(t.y * pm));
@@ -690,12 +692,45 @@ __device__ __forceinline__ int sturm_count_below(const double2* de, int np, doub
             const int ex = __builtin_amdgcn_frexp_exp(fabs(pc) > fabs(pm) ? pc : pm);
             pc = ldexp(pc, -ex);
             pm = ldexp(pm, -ex);
+            esum += ex;
         }
     }
     for (; i < np; ++i) { term(i); ++fresh; }
     flush();
+    if (last) { *last = pc; *last_exp = esum; }
     return cnt;
 }
+
+// Where a straight line through the characteristic polynomial's values pa 2^ea at lo and pb 2^eb at hi (of opposite
+// signs: one simple eigenvalue between them) crosses zero.
+__device__ __forceinline__ double interpolated_root(double lo, double hi, double pa, int ea, double pb, int eb) {
+    double ma = fabs(pa), mb = fabs(pb);
+    const int d = max(-1000, min(1000, ea - eb));
+    if (d >= 0) mb = ldexp(mb, -d); else ma = ldexp(ma, d);
+    const double sum = ma + mb;
+    const double rho = sum > 0.0 ? ma / sum : 0.5;
+    return lo + (hi - lo) * rho;
+}
+
+// Points of a search round spaced geometrically around the estimate c inside [lo, hi]: HALF points on either side, at the
+// distances delta ratio^k, k = 0 .. HALF - 1, the ratio such that the last one reaches the farther end of the bracket
+// (clipped to the bracket).  k-th point below c in lane HALF - 1 - k of the group, k-th above in lane HALF + k: the
+// points rise with the lane.  The bracket that comes out of the round is about as wide as the estimate was off.
+template <int HALF>
+__device__ __forceinline__ double geometric_point(int g, double lo, double hi, double c, double delta) {
+    const float span = (float)fmax(hi - c, c - lo);
+    const float lr = fmaxf(__log2f(span / (float)delta) * (1.0f / (float)(HALF - 1)), 0.05f);
+    const int k = g < HALF ? HALF - 1 - g : g - HALF;
+    const double d = delta * (double)exp2f(lr * (float)k);
+    return g < HALF ? fmax(c - d, lo) : fmin(c + d, hi);
+}
+// A bracket narrower than this (after two uniform rounds, as a rule) is searched geometrically around the interpolated
+// root when it holds one simple eigenvalue; a geometric round that gained less than a uniform one would have sends
+// the next one back to uniform points (a second eigenvalue close below the bracket bends the polynomial).
+#ifndef STURM_GEO_BELOW
+#define STURM_GEO_BELOW 0.03
+#endif
+constexpr double STURM_GEOMETRIC_BELOW = STURM_GEO_BELOW;
 
 // Sturm multisection for the largest eigenvalue of the symmetric tridiagonal matrix
 // (L.de[k] = (d_k, e_k^2), k < np) inside [lo, hi]: lane t counts the eigenvalues below x_t.
@@ -703,22 +738,38 @@ __device__ __forceinline__ int sturm_count_below(const double2* de, int np, doub
 template <class LDS, bool PRIO = false>
 __device__ __forceinline__ double sturm_largest_wave(const LDS& L, int np, int lane, double lo, double hi, int rounds,
                                                      SolvePriority<PRIO>* prio = nullptr) {
+    bool geometric = false;
+    double c = 0.0;
     for (int r = 0; r < rounds; ++r) {
-        if (hi - lo <= 1e-11 * hi) break;
+        const double h = hi - lo;
+        if (h <= 1e-11 * hi) break;
         if (prio) prio->spend(4 * np);
-        const double w = (hi - lo) * (1.0 / 65.0);
-        const double x = lo + w * (double)(lane + 1);
-        const int cnt = sturm_count_below(L.de, np, x);
+        const double x = geometric ? geometric_point<WAVE / 2>(lane, lo, hi, c, 0.4e-11 * hi)
+                                   : lo + h * (1.0 / 65.0) * (double)(lane + 1);
+        double pl;
+        int pe;
+        const int cnt = sturm_count_below(L.de, np, x, &pl, &pe);
         const uint64_t all = ballot64(cnt >= np);
+        bool simple = false;                       // exactly one eigenvalue inside the new bracket, its ends in lanes t - 1, t
+        int t = 0;
         if (all == 0) {
             lo = readlane_d(x, WAVE - 1);
         } else {
-            const int t = __ffsll((unsigned long long)all) - 1;
+            t = __ffsll((unsigned long long)all) - 1;
             const double xh = readlane_d(x, t);
             const double xl = readlane_d(x, t > 0 ? t - 1 : 0);
             hi = xh;
-            if (t > 0) lo = xl;
+            if (t > 0) {
+                lo = xl;
+                simple = np - __builtin_amdgcn_readlane(cnt, t - 1) == 1;
+            }
         }
+        const double hn = hi - lo;
+        const bool gained = !geometric || hn * 65.0 <= h;
+        geometric = simple && gained && hn <= STURM_GEOMETRIC_BELOW;
+        if (geometric)
+            c = interpolated_root(lo, hi, readlane_d(pl, t - 1), __builtin_amdgcn_readlane(pe, t - 1), readlane_d(pl, t),
+                                  __builtin_amdgcn_readlane(pe, t));
     }
     return 0.5 * (lo + hi);
 }
@@ -1039,6 +1090,10 @@ __device__ __forceinline__ double mu_max_pair_wave(uint32_t crow, int np, int np
     double lo = (double)(dmax + 1) * (1.0 - 1e-13) - 1e-13;
     double hi = (double)min(npb, 2 * dmax) * (1.0 + 1e-13) + 1e-13;
     const double2* de = L.de + (lane & 32);
+    // (Uniform rounds only.  The geometric rounds of sturm_largest_wave would make a half's result depend on its partner:
+    // the recurrence runs over the larger problem's rows, the padding multiplies the polynomial's value by powers of x,
+    // and the interpolated root moves in its last bits -- while lambda2 of an env must not depend on which env shares
+    // its wave, or a batch and its shards would differ.  Measured gain of having them here: 0.1 % of a step.)
     for (int r = 0; r < rounds; ++r) {
         const bool active = (hi - lo) > 1e-11 * hi;
         if (ballot64(active) == 0) break;
