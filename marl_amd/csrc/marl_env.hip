@@ -1882,7 +1882,8 @@ __global__ __launch_bounds__(1024) void solve_order_kernel(int E, MarlEnvState S
         const int nitems = nbig + ((total - nbig + 1) >> 1);
         const bool by_priority = prio_slots > 0 && nitems * 100 >= SOLVE_PRIO_ITEMS_MIN * prio_slots &&
                                  nitems * 100 <= SOLVE_PRIO_ITEMS_MAX * prio_slots;
-        if (blockIdx.x == 0 && threadIdx.x == 0) S.solve_hist[SOLVE_HIST_TOTAL + 2] = by_priority ? 1 : 0;
+        // (the verdict: 0, or the number of SIMDs the solve blocks go round)
+        if (blockIdx.x == 0 && threadIdx.x == 0) S.solve_hist[SOLVE_HIST_TOTAL + 2] = by_priority ? prio_slots / 4 : 0;
     }
     __syncthreads();
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1991,8 +1992,20 @@ __device__ __forceinline__ void solve_block(const MarlEnvParams& P, const MarlEn
         // Whether this launch schedules by priority was decided by the order kernel, from the number of its items.  Two
         // copies of the solver, one taken by every block of a launch: keeping the books of the priority costs a solve
         // 2-3 % even when no level is ever changed.
-        if (S.solve_hist[SOLVE_HIST_TOTAL + 2]) solve_item<NPAD, true, LANCZOS>(P, S, io, (int)blockIdx.x, nbig, total, lane, L);
-        else solve_item<NPAD, false, LANCZOS>(P, S, io, (int)blockIdx.x, nbig, total, lane, L);
+        const int simds = S.solve_hist[SOLVE_HIST_TOTAL + 2];
+        if (simds) {
+#ifndef SOLVE_NO_SNAKE
+            // One-wave workgroups go to the SIMDs in turn, block b to SIMD b mod simds: with the items in descending order
+            // SIMD 0 would get the largest of every round.  Every second round runs backwards instead, so that the sums
+            // per SIMD -- which is what a launch scheduled by priority takes -- are level.
+            const int b = (int)blockIdx.x, q = b / simds, first = q * simds;
+            const int len = min(simds, nitems - first);
+            const int item = (q & 1) ? first + (len - 1 - (b - first)) : b;
+#else
+            const int item = (int)blockIdx.x;
+#endif
+            solve_item<NPAD, true, LANCZOS>(P, S, io, item, nbig, total, lane, L);
+        } else solve_item<NPAD, false, LANCZOS>(P, S, io, (int)blockIdx.x, nbig, total, lane, L);
     } else {
         solve_item<NPAD, false, LANCZOS>(P, S, io, (int)blockIdx.x, nbig, total, lane, L);
     }
